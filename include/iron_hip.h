@@ -1,0 +1,205 @@
+/*
+ * iron_hip.h -- C ABI of libiron_hip.so, the MI355X (gfx950) implementation of IRON's
+ * stage-2 forward render path (sphere-trace + normal/material MLPs + co-located GGX).
+ *
+ * The reference (arthurlirui/IRON) has no FFI layer: its boundary for this path is the Python
+ * operator surface of models/raytracer.py, models/renderer_ggx.py, models/rendering_func.py
+ * and models/fields.py.  Each entry point below names the reference function it replaces
+ * (file:line, relative to the reference root); iron_amd/*.py binds them with ctypes and
+ * re-exposes the reference's names.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer unless marked HOST.
+ *   - all arrays are contiguous row-major fp32 unless noted; masks are uint8 (0/1), i.e. the
+ *     storage of a torch.bool tensor.
+ *   - all buffers are caller-allocated and caller-owned; the library keeps nothing past the call
+ *     except the packed weight copy made by iron_net_create().
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     the host, nothing allocates (graph-capturable) except iron_net_create/destroy.
+ *   - return value: IRON_OK (0) or a negative iron_status; no exceptions / aborts cross the ABI.
+ *   - handles are immutable after create and may be shared between host threads.
+ */
+#ifndef IRON_HIP_H
+#define IRON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRON_ABI_VERSION 1
+
+typedef enum iron_status {
+    IRON_OK = 0,
+    IRON_ERR_BAD_ARG = -1,      /* null pointer, negative size, misaligned buffer              */
+    IRON_ERR_UNSUPPORTED = -2,  /* network shape / mode the kernels are not built for          */
+    IRON_ERR_HIP = -3,          /* a HIP runtime call failed; see iron_last_hip_error()        */
+    IRON_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                                    */
+    IRON_ERR_WORKSPACE = -5     /* workspace too small                                         */
+} iron_status;
+
+int iron_version(void);
+const char* iron_strerror(int status);
+/* hipError_t (as int) of the last failing HIP call on this host thread, 0 if none. */
+int iron_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Networks.  Replaces the parameter side of models/fields.py:9-98 (SDFNetwork) and :141-239
+ * (RenderingNetwork).  Input format = the reference state_dict: per linear layer `weight_v`
+ * [out,in], `weight_g` [out] (old-style weight_norm, fields.py:75-76; NULL for a plain layer,
+ * then weight_v is the weight itself) and `bias` [out].  The library folds the weight norm
+ * (W = v * g/||v||_row) and re-packs into its MFMA fragment layout on the device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct iron_net iron_net_t; /* opaque */
+
+typedef struct iron_linear {
+    const float* weight_v; /* [out_dim, in_dim] */
+    const float* weight_g; /* [out_dim] or NULL  */
+    const float* bias;     /* [out_dim]          */
+    int32_t out_dim;
+    int32_t in_dim;
+} iron_linear;
+
+enum { IRON_NET_SDF = 0, IRON_NET_RENDER = 1 };
+enum { IRON_MODE_IDR = 0, IRON_MODE_NO_VIEW_DIR = 1, IRON_MODE_NO_NORMAL = 2, IRON_MODE_POINTS_ONLY = 3 };
+
+typedef struct iron_net_desc {
+    int32_t kind;          /* IRON_NET_SDF | IRON_NET_RENDER                                        */
+    int32_t n_linear;      /* number of linear layers (= n_layers + 1)                              */
+    int32_t d_hidden;      /* hidden width (256)                                                    */
+    int32_t d_out;         /* SDF: 257 (sdf + feature); RENDER: 1..3                                */
+    int32_t multires;      /* PE levels on points (SDF: 6)                                          */
+    int32_t multires_view; /* RENDER: PE levels on view_dirs (<=0: none)                            */
+    int32_t skip_layer;    /* index of the skip-concat layer, -1 if none (SDF: 4)                   */
+    int32_t mode;          /* RENDER: IRON_MODE_*                                                   */
+    int32_t d_feature;     /* RENDER: width of the feature vector input (256)                       */
+    int32_t squeeze_out;   /* RENDER: apply squeeze_out_scale*sigmoid()                             */
+    float squeeze_out_scale;
+    float output_bias;     /* RENDER: x = output_scale * (x + output_bias)                          */
+    float output_scale;
+    float scale;           /* SDF: input scale (fields.py:83,98)                                    */
+} iron_net_desc;
+
+/* Build a packed network on the current device.  `layers` is a HOST array of n_linear entries
+ * whose pointers are DEVICE pointers.  Synchronises `stream` before returning (the source
+ * tensors may be freed afterwards).  Must be re-run when parameters change. */
+int iron_net_create(iron_net_t** out, const iron_net_desc* desc, const iron_linear* layers, void* stream);
+int iron_net_destroy(iron_net_t* net);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched field queries
+ * ------------------------------------------------------------------------------------------- */
+/* SDFNetwork.forward / .sdf (models/fields.py:82-104).  x [n,3] -> out [n,out_cols],
+ * out_cols = 1 (sdf only) or d_out (sdf + feature). */
+int iron_sdf_forward(const iron_net_t* sdf, const float* x, int64_t n, float* out, int32_t out_cols, void* stream);
+
+/* SDFNetwork.get_all(x, is_training=False) (models/fields.py:120-137): sdf [n], feature
+ * [n,d_out-1], grad = d sdf/dx [n,3] (forward-mode, no autograd graph).  Any output may be NULL. */
+int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sdf_out, float* feature,
+                     float* grad, void* stream);
+
+/* RenderingNetwork.forward (models/fields.py:203-239).  view_dirs may be NULL for modes that do
+ * not read it.  out [n,d_out]. */
+int iron_render_forward(const iron_net_t* net, const float* points, const float* normals,
+                        const float* view_dirs, const float* features, int64_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise geometry
+ * ------------------------------------------------------------------------------------------- */
+/* Camera.get_rays (models/raytracer.py:254-286).  k_inv3 = K^-1[:3,:3], c2w34 = C2W[:3,:4], both
+ * HOST row-major.  uv [n,2] -> ray_o [n,3], ray_d [n,3] (normalised), ray_d_norm [n]. */
+int iron_camera_rays(const float* k_inv3, const float* c2w34, const float* uv, int64_t n, float* ray_o,
+                     float* ray_d, float* ray_d_norm, void* stream);
+
+/* intersect_sphere (models/raytracer.py:223-237). */
+int iron_intersect_sphere(const float* ray_o, const float* ray_d, int64_t n, float r, uint8_t* mask,
+                          float* near, float* far, void* stream);
+
+/* GGXColocatedRenderer.forward (models/renderer_ggx.py:82-146).  distance [n], normal/viewdir
+ * [n,3], albedos [n,3], roughness [n]; tab_trans [5000], tab_diff_trans [50] (models/ggx/*.txt). */
+int iron_ggx_colocated(float light, const float* distance, const float* normal, const float* viewdir,
+                       const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                       const float* tab_trans, const float* tab_diff_trans, int64_t n, float* diffuse_rgb,
+                       float* specular_rgb, float* rgb, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sphere tracer.  Replaces RayTracer.forward = sphere_tracing + ray_sampler + rootfind
+ * (models/raytracer.py:45-220) for a batch of n rays, with the per-call chunking of
+ * raytrace_pixels (:378-392) expressed as `chunk`: rays [k*chunk, (k+1)*chunk) share the
+ * bisection iteration count exactly as one reference RayTracer.forward call does.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct iron_trace_params {
+    float sdf_threshold;          /* 5e-5 */
+    int32_t sphere_tracing_iters; /* 16   */
+    int32_t n_steps;              /* 128  */
+    int64_t chunk;                /* rays per reference call (<=0: all n in one chunk) */
+} iron_trace_params;
+
+typedef struct iron_trace_stats { /* written to DEVICE memory, all int64 */
+    int64_t n_evals;       /* SDF point evaluations actually performed                          */
+    int64_t n_sphere_conv; /* rays convergent after sphere tracing                              */
+    int64_t n_sampler;     /* rays handed to the dense sampler                                  */
+    int64_t n_bisect;      /* rays bisected                                                     */
+    int64_t n_conv;        /* convergent rays at the end                                        */
+    int64_t reserved[3];
+} iron_trace_stats;
+
+size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params* p);
+
+/* lin_steps: n_steps floats = torch.linspace(0,1,n_steps) (raytracer.py:144-146), DEVICE.
+ * Outputs: conv uint8[n], points [n,3], sdf [n], dist [n] (state of non-convergent rays as the
+ * reference leaves it).  stats may be NULL.  chunk_iters_io (int32[n_chunks], DEVICE) may be NULL;
+ * see iron_trace_phase for the multi-rank protocol. */
+int iron_trace(const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps, const float* ray_o,
+               const float* ray_d, const float* near, const float* far, const uint8_t* work, int64_t n,
+               uint8_t* conv, float* points, float* sdf_out, float* dist, iron_trace_stats* stats,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Multi-rank form: rays of one reference chunk may live on several ranks, so the chunk-global
+ * bisection count needs one MAX all-reduce between the two halves.  phase 0 = sphere trace +
+ * sampler + per-ray bisection, writing each local chunk's own count to chunk_iters[n_chunks];
+ * the caller all-reduces (MAX) that array, then phase 1 finishes the bisection with it.
+ * ray_index [n] (int64, may be NULL = identity) gives each ray's position in the full image so
+ * that chunk = ray_index / p->chunk. */
+int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps,
+                     const float* ray_o, const float* ray_d, const float* near, const float* far,
+                     const uint8_t* work, const int64_t* ray_index, int64_t n, int32_t* chunk_iters,
+                     int64_t n_chunks, uint8_t* conv, float* points, float* sdf_out, float* dist,
+                     iron_trace_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shading.  Replaces render_normal_and_color (models/raytracer.py:593-662) with the driver's GGX
+ * render_fn (render_surface.py:117-156): for every ray with conv != 0: get_all -> normalise ->
+ * get_materials (models/rendering_func.py:5-16) -> GGXColocatedRenderer; other rays get zeros.
+ * Outputs are full-size [n,3] / [n]; any may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct iron_shade_nets {
+    const iron_net_t* sdf;
+    const iron_net_t* diffuse_albedo;
+    const iron_net_t* specular_albedo;
+    const iron_net_t* specular_roughness;
+} iron_shade_nets;
+
+typedef struct iron_shade_out {
+    float* color;              /* [n,3] rgb                    */
+    float* diffuse_color;      /* [n,3]                        */
+    float* specular_color;     /* [n,3]                        */
+    float* diffuse_albedo;     /* [n,3]                        */
+    float* specular_albedo;    /* [n,3]                        */
+    float* specular_roughness; /* [n]                          */
+    float* normal;             /* [n,3] normalised             */
+} iron_shade_out;
+
+size_t iron_shade_workspace_bytes(int64_t n);
+
+int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t is_metal, const float* tab_trans,
+                   const float* tab_diff_trans, const float* ray_o, const float* ray_d, const float* points,
+                   const uint8_t* conv, int64_t n, const iron_shade_out* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRON_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libiron_hip.so (include/iron_hip.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libiron_hip.so")
+
+IRON_OK = 0
+IRON_NET_SDF, IRON_NET_RENDER = 0, 1
+MODES = {"idr": 0, "no_view_dir": 1, "no_normal": 2, "points_only": 3}
+
+
+class IronError(RuntimeError):
+    pass
+
+
+class iron_linear(C.Structure):
+    _fields_ = [("weight_v", C.c_void_p), ("weight_g", C.c_void_p), ("bias", C.c_void_p),
+                ("out_dim", C.c_int32), ("in_dim", C.c_int32)]
+
+
+class iron_net_desc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_linear", C.c_int32), ("d_hidden", C.c_int32), ("d_out", C.c_int32),
+                ("multires", C.c_int32), ("multires_view", C.c_int32), ("skip_layer", C.c_int32),
+                ("mode", C.c_int32), ("d_feature", C.c_int32), ("squeeze_out", C.c_int32),
+                ("squeeze_out_scale", C.c_float), ("output_bias", C.c_float), ("output_scale", C.c_float),
+                ("scale", C.c_float)]
+
+
+class iron_trace_params(C.Structure):
+    _fields_ = [("sdf_threshold", C.c_float), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
+                ("chunk", C.c_int64)]
+
+
+class iron_shade_nets(C.Structure):
+    _fields_ = [("sdf", C.c_void_p), ("diffuse_albedo", C.c_void_p), ("specular_albedo", C.c_void_p),
+                ("specular_roughness", C.c_void_p)]
+
+
+class iron_shade_out(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("diffuse_color", C.c_void_p), ("specular_color", C.c_void_p),
+                ("diffuse_albedo", C.c_void_p), ("specular_albedo", C.c_void_p),
+                ("specular_roughness", C.c_void_p), ("normal", C.c_void_p)]
+
+
+TRACE_STATS_FIELDS = ("n_evals", "n_sphere_conv", "n_sampler", "n_bisect", "n_conv", "r0", "r1", "r2")
+
+# every symbol include/iron_hip.h declares: name -> (restype, argtypes)
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SYMBOLS = {
+    "iron_version": (C.c_int, []),
+    "iron_strerror": (C.c_char_p, [C.c_int]),
+    "iron_last_hip_error": (C.c_int, []),
+    "iron_net_create": (C.c_int, [C.POINTER(_P), C.POINTER(iron_net_desc), C.POINTER(iron_linear), _P]),
+    "iron_net_destroy": (C.c_int, [_P]),
+    "iron_sdf_forward": (C.c_int, [_P, _P, _I64, _P, _I32, _P]),
+    "iron_sdf_get_all": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "iron_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "iron_camera_rays": (C.c_int, [C.POINTER(_F), C.POINTER(_F), _P, _I64, _P, _P, _P, _P]),
+    "iron_intersect_sphere": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
+    "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_trace_workspace_bytes": (_SZ, [_I64, C.POINTER(iron_trace_params)]),
+    "iron_trace": (C.c_int, [_P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
+                             _P, _SZ, _P]),
+    "iron_trace_phase": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _I64, _P,
+                                   _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "iron_shade_workspace_bytes": (_SZ, [_I64]),
+    "iron_shade_ggx": (C.c_int, [C.POINTER(iron_shade_nets), _F, _I32, _P, _P, _P, _P, _P, _P, _I64,
+                                 C.POINTER(iron_shade_out), _P, _SZ, _P]),
+}
+
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise IronError(
+                "libiron_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (iron_amd has no CPU / eager fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.iron_version() != 1:
+            raise IronError("libiron_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    if status != IRON_OK:
+        lib = load()
+        msg = lib.iron_strerror(status).decode()
+        if status == -3:
+            msg += " [hipError_t=%d]" % lib.iron_last_hip_error()
+        raise IronError("libiron_hip: %s" % msg)
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """The product path is HIP-only: refuse CPU tensors instead of silently computing elsewhere."""
+    if not t.is_cuda:
+        raise IronError("%s must be a CUDA (ROCm) tensor: iron_amd has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise IronError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()

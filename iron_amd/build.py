@@ -1,0 +1,81 @@
+"""Builds iron_amd/csrc/libiron_hip.so (gfx950 only) with hipcc, in-tree.
+
+Used by __graft_entry__.build(); hipcc cross-compiles without a GPU.  The .so is git-ignored but
+travels with the tree to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libiron_hip.so")
+OBJ_DIR = os.path.join(CSRC, "build")
+
+SOURCES = ["pack.hip", "sdf_forward.hip", "pointwise.hip", "trace.hip", "shade.hip"]
+HEADERS = ["iron_common.h", "mlp_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
+
+BASE_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    # the pointwise glue must round like the reference's separate torch mul/add kernels
+    "-ffp-contract=off",
+    "-Wno-comment", "-Wno-unused-result",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
+
+
+def _digest(extra_flags) -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        p = os.path.join(CSRC, name)
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                h.update(f.read())
+    h.update(" ".join(BASE_FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
+    """Compile every .hip source and link the shared library; returns its path."""
+    extra_flags = list(extra_flags) + os.environ.get("IRON_HIPCC_FLAGS", "").split()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    stamp = os.path.join(OBJ_DIR, "stamp")
+    dig = _digest(extra_flags)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = _hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + BASE_FLAGS + extra_flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), 6)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print("built", LIB, file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

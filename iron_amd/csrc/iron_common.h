@@ -1,0 +1,103 @@
+// Shared host/device declarations for libiron_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/iron_hip.h"
+
+namespace iron {
+
+// ---- fixed geometry of the MFMA path --------------------------------------------------------
+// One wave evaluates a tile of 32 points with v_mfma_f32_32x32x2_f32: points live on lanes
+// (lane & 31), features in registers.  A 32-feature tile is 16 registers per lane; feature f of
+// the tile sits in register r = (f&3) + 4*(f>>3) of lane-half h = (f>>2)&1  (the MFMA C/D map
+// row = (r&3) + 8*(r>>2) + 4*h), which is also exactly the B-operand slot order when the tile is
+// fed back as the next layer's input, so activations never leave registers.
+constexpr int kTile = 32;
+constexpr int kHidden = 256;
+constexpr int kHidTiles = kHidden / kTile;  // 8
+constexpr int kPairs = kHidTiles / 2;       // output tiles are produced two at a time
+
+// float4 counts of the packed blobs
+constexpr int kF4PerHidLayer = kPairs * kHidTiles * 4 * 2 * 64;  // 16384 float4 = 256 KiB
+constexpr int kF4PerBiasLayer = kHidTiles * 2 * 4;               // 64 float4
+
+// Head ("non-hidden") inputs: vec3 sources with optional NeRF positional encoding.  A source with
+// L levels occupies 2 + 3L register slots: slot0 = (x | y), slot1 = (z | 0), then per (level k,
+// component c) one slot holding (sin | cos)(2^k * v_c) in lane-half (0 | 1).
+__host__ __device__ constexpr int head_slots(int levels) { return 2 + 3 * (levels > 0 ? levels : 0); }
+__host__ __device__ constexpr int pe_width(int levels) { return 3 + 6 * (levels > 0 ? levels : 0); }
+
+// canonical (reference) column of head slot `s`, lane-half h, for a source with `levels`;
+// -1 = unused slot.  Reference order (models/embedder.py:27-36): [v, sin(2^0 v), cos(2^0 v), ...].
+__host__ __device__ inline int head_slot_column(int s, int h, int levels) {
+    if (s == 0) return h;                 // x | y
+    if (s == 1) return h ? -1 : 2;        // z | -
+    int idx = s - 2;
+    int k = idx / 3, c = idx % 3;
+    if (k >= levels) return -1;
+    return 3 + 6 * k + 3 * h + c;
+}
+
+// Packed arrays are addressed as byte offsets into one blob through a buffer resource (SGPR
+// descriptor + one per-lane VGPR offset + scalar offsets), so weight streaming costs no address VGPRs.
+struct SdfNetDev {
+    const void* blob;
+    uint32_t blob_bytes;
+    uint32_t w_pe0;      // layer 0 on PE slots           [pairs][NQ][2][64] float4
+    uint32_t w_hid;      // hidden layers 1..n-2          [L][pairs][8][4][2][64]
+    uint32_t w_pe_skip;  // skip layer, PE part           [pairs][NQ][2][64]
+    uint32_t bias;       // layers 0..n-2                 [L+1][8][2][4]
+    uint32_t w_last;     // last layer row 0              [8][2][4]
+    uint32_t w_feat;     // last layer rows 1..256        [pairs][8][4][2][64]  (0 = absent)
+    uint32_t b_feat;     //                               [8][2][4]
+    float b_last;
+    float scale;
+    int n_hidden_layers;      // number of softplus layers (8)
+    int skip_layer;           // 4
+};
+
+// Material net: head (<= 6 quads of slots) + 256 features -> 256 x (n-1) -> d_out (<=3)
+struct RenderNetDev {
+    const void* blob;
+    uint32_t blob_bytes;
+    uint32_t w_head0;    // layer 0, head part            [pairs][NQ][2][64]
+    uint32_t w_feat0;    // layer 0, feature part         [pairs][8][4][2][64]
+    uint32_t w_hid;      // layers 1..n-2                 [L][pairs][8][4][2][64]
+    uint32_t bias;       // layers 0..n-2                 [L+1][8][2][4]
+    uint32_t w_last;     // last layer rows 0..d_out-1    [3][8][2][4]
+    float b_last[3];
+    int d_out;
+    int n_hidden_layers;      // number of relu layers (4)
+    int head_quads;           // NQ
+    // head sources, in slot order
+    int n_src;
+    int src_kind[3];          // 0 points, 1 view_dirs, 2 normals
+    int src_levels[3];
+    int squeeze_out;
+    float squeeze_out_scale, output_bias, output_scale;
+};
+
+}  // namespace iron
+
+struct iron_net {
+    iron_net_desc desc;
+    void* blob;           // device allocation holding every packed array
+    size_t blob_bytes;
+    iron::SdfNetDev sdf;
+    iron::RenderNetDev rnd;
+    int device;
+};
+
+namespace iron {
+extern thread_local int g_last_hip_error;
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return IRON_ERR_HIP;
+}
+}  // namespace iron
+
+#define IRON_HIP_TRY(expr)                                  \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return ::iron::hip_fail(_e);  \
+    } while (0)

@@ -1,0 +1,404 @@
+// Network handles: weight-norm folding + repacking of reference state_dict tensors into the MFMA
+// fragment layout (iron_common.h).  Replaces the parameter side of models/fields.py:9-98,141-201.
+#include <math.h>
+#include <string.h>
+#include <new>
+#include "iron_common.h"
+
+namespace iron {
+
+thread_local int g_last_hip_error = 0;
+
+// scale[o] = g[o] / ||v[o,:]||_2   (old-style weight_norm, dim=0; fields.py:75-76), 1 if g == NULL
+__global__ void k_row_scale(const float* __restrict__ v, const float* __restrict__ g, int out_dim, int in_dim,
+                            float* __restrict__ scale) {
+    const int o = blockIdx.x;
+    if (o >= out_dim) return;
+    if (g == nullptr) {
+        if (threadIdx.x == 0) scale[o] = 1.0f;
+        return;
+    }
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < in_dim; k += 64) {
+        const float a = v[(size_t)o * in_dim + k];
+        s = fmaf(a, a, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) scale[o] = g[o] / sqrtf(s);
+}
+
+struct PackSrc {
+    const float* w;      // [rows, ld] row-major weight_v
+    const float* scale;  // per-row fold factor
+    int ld;
+    int rows_valid;      // rows >= this are zero padding
+    int row_off;         // first source row
+    float mul;           // extra factor (1/sqrt(2) for the skip layer)
+};
+
+// dst [pairs][8][4][2][64] float4 : lane (i,h) of (pair p, which w, in-tile ti, quad q) holds
+//   W[32*(2p+w) + i][col_off + 32*ti + 8*q + 4*h + 0..3]
+__global__ void k_pack_hidden(float4* __restrict__ dst, PackSrc s, int col_off, int cols_valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPairs * kHidTiles * 4 * 2 * 64) return;
+    const int lane = e & 63;
+    const int w = (e >> 6) & 1;
+    const int q = (e >> 7) & 3;
+    const int ti = (e >> 9) & 7;
+    const int p = e >> 12;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * (2 * p + w) + i;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = 32 * ti + 8 * q + 4 * h + c;
+        float x = 0.0f;
+        if (row < s.rows_valid && col < cols_valid)
+            x = s.w[(size_t)(s.row_off + row) * s.ld + col_off + col] * s.scale[s.row_off + row] * s.mul;
+        v[c] = x;
+    }
+    dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+struct HeadSrcs {
+    int n;
+    int slot_base[3];
+    int levels[3];
+    int col_off[3];
+};
+
+// dst [pairs][NQ][2][64] float4 : lane (i,h) of (pair, quad q, which w) holds the weights of head
+// slots 4q..4q+3 (their lane-half-h columns) for output row 32*(2p+w)+i
+__global__ void k_pack_head(float4* __restrict__ dst, PackSrc s, HeadSrcs hs, int nq) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPairs * nq * 2 * 64) return;
+    const int lane = e & 63;
+    const int w = (e >> 6) & 1;
+    const int q = (e >> 7) % nq;
+    const int p = (e >> 7) / nq;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * (2 * p + w) + i;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int slot = 4 * q + c;
+        float x = 0.0f;
+        for (int k = 0; k < hs.n; ++k) {
+            const int local = slot - hs.slot_base[k];
+            if (local >= 0 && local < head_slots(hs.levels[k])) {
+                const int col = head_slot_column(local, h, hs.levels[k]);
+                if (col >= 0 && row < s.rows_valid)
+                    x = s.w[(size_t)(s.row_off + row) * s.ld + hs.col_off[k] + col] * s.scale[s.row_off + row] * s.mul;
+            }
+        }
+        v[c] = x;
+    }
+    dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// dst [8][2][16] floats: element (tile, h, r) = bias[row_off + 32*tile + (r&3) + 8*(r>>2) + 4*h]
+__global__ void k_pack_bias(float* __restrict__ dst, const float* __restrict__ bias, int row_off, int rows_valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kHidTiles * 2 * 16) return;
+    const int r = e & 15, h = (e >> 4) & 1, t = e >> 5;
+    const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+    dst[e] = row < rows_valid ? bias[row_off + row] : 0.0f;
+}
+
+// dst [8][2][16] floats: element (tile, h, r) = W[row][col_off + 32*tile + (r&3) + 8*(r>>2) + 4*h] * scale[row]
+__global__ void k_pack_row(float* __restrict__ dst, PackSrc s, int row, int col_off, int cols_valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kHidTiles * 2 * 16) return;
+    const int r = e & 15, h = (e >> 4) & 1, t = e >> 5;
+    const int col = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+    dst[e] = col < cols_valid ? s.w[(size_t)row * s.ld + col_off + col] * s.scale[row] * s.mul : 0.0f;
+}
+
+static inline size_t align_f4(size_t n_f4) { return (n_f4 + 15) & ~(size_t)15; }
+
+}  // namespace iron
+
+using namespace iron;
+
+extern "C" int iron_version(void) { return IRON_ABI_VERSION; }
+
+extern "C" int iron_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" const char* iron_strerror(int status) {
+    switch (status) {
+        case IRON_OK: return "ok";
+        case IRON_ERR_BAD_ARG: return "bad argument (null pointer, negative size or misaligned buffer)";
+        case IRON_ERR_UNSUPPORTED: return "unsupported network shape or mode for the gfx950 kernels";
+        case IRON_ERR_HIP: return "HIP runtime error (see iron_last_hip_error)";
+        case IRON_ERR_NO_DEVICE: return "no gfx950 device visible";
+        case IRON_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown iron status";
+    }
+}
+
+static int check_device(int* dev_out) {
+    int dev = 0;
+    IRON_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    IRON_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IRON_ERR_NO_DEVICE;
+    *dev_out = dev;
+    return IRON_OK;
+}
+
+
+namespace {
+
+struct Blob {
+    size_t n_f4 = 0;
+    size_t take(size_t f4) { size_t o = n_f4; n_f4 += align_f4(f4); return o; }
+};
+
+// per-layer fold factors live in the blob too (kept: cheap, and lets create stay allocation-light)
+int fold_scales(const iron_linear* L, int nl, float* scale_base, size_t* scale_off, hipStream_t st) {
+    size_t off = 0;
+    for (int l = 0; l < nl; ++l) {
+        scale_off[l] = off;
+        hipLaunchKernelGGL(k_row_scale, dim3(L[l].out_dim), dim3(64), 0, st, L[l].weight_v, L[l].weight_g,
+                           L[l].out_dim, L[l].in_dim, scale_base + off);
+        off += (size_t)L[l].out_dim;
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+inline PackSrc make_src(const iron_linear& l, const float* scale, int rows_valid, int row_off, float mul) {
+    PackSrc s;
+    s.w = l.weight_v; s.scale = scale; s.ld = l.in_dim; s.rows_valid = rows_valid; s.row_off = row_off; s.mul = mul;
+    return s;
+}
+
+inline void launch_pack_hidden(float4* dst, const PackSrc& s, int col_off, int cols_valid, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_hidden, dim3(kF4PerHidLayer / 256), dim3(256), 0, st, dst, s, col_off, cols_valid);
+}
+inline void launch_pack_head(float4* dst, const PackSrc& s, const HeadSrcs& hs, int nq, hipStream_t st) {
+    const int n = kPairs * nq * 2 * 64;
+    hipLaunchKernelGGL(k_pack_head, dim3((n + 255) / 256), dim3(256), 0, st, dst, s, hs, nq);
+}
+inline void launch_pack_bias(float4* dst, const float* bias, int row_off, int rows_valid, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)dst, bias, row_off, rows_valid);
+}
+inline void launch_pack_row(float4* dst, const PackSrc& s, int row, int col_off, int cols_valid, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)dst, s, row, col_off, cols_valid);
+}
+
+const float kInvSqrt2 = 1.0f / 1.41421356237309504880f;  // activations / np.sqrt(2) folded into W
+
+int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int nl = d.n_linear;
+    const int pe = pe_width(d.multires);
+    const int skip = d.skip_layer;
+    if (d.d_hidden != kHidden || d.multires != 6 || nl < 3 || nl > 17) return IRON_ERR_UNSUPPORTED;
+    if (!(skip == -1 || (skip >= 2 && skip <= nl - 2))) return IRON_ERR_UNSUPPORTED;
+    if (!(d.d_out == 1 || d.d_out == kHidden + 1)) return IRON_ERR_UNSUPPORTED;
+    if (!(d.scale > 0.0f)) return IRON_ERR_BAD_ARG;
+    for (int l = 0; l < nl; ++l) {
+        if (!L[l].weight_v || !L[l].bias) return IRON_ERR_BAD_ARG;
+        const int want_in = (l == 0) ? pe : kHidden;
+        int want_out = (l == nl - 1) ? d.d_out : kHidden;
+        if (l + 1 == skip) want_out = kHidden - pe;
+        if (L[l].in_dim != want_in || L[l].out_dim != want_out) return IRON_ERR_UNSUPPORTED;
+    }
+    const int nq = head_slots(d.multires) / 4;  // 5
+    Blob b;
+    b.take(16);  // offset 0 is reserved as "absent"
+    const size_t o_pe0 = b.take((size_t)kPairs * nq * 2 * 64);
+    const size_t o_hid = b.take((size_t)(nl - 2) * kF4PerHidLayer);
+    const size_t o_pes = b.take((size_t)kPairs * nq * 2 * 64);
+    const size_t o_bias = b.take((size_t)(nl - 1) * kF4PerBiasLayer);
+    const size_t o_last = b.take(kF4PerBiasLayer);
+    const size_t o_feat = b.take(kF4PerHidLayer);
+    const size_t o_bfeat = b.take(kF4PerBiasLayer);
+    size_t n_scale = 0;
+    for (int l = 0; l < nl; ++l) n_scale += (size_t)L[l].out_dim;
+    const size_t o_scale = b.take((n_scale + 3) / 4);
+
+    net->blob_bytes = b.n_f4 * sizeof(float4);
+    IRON_HIP_TRY(hipMalloc(&net->blob, net->blob_bytes));
+    IRON_HIP_TRY(hipMemsetAsync(net->blob, 0, net->blob_bytes, st));
+    float4* base = (float4*)net->blob;
+    float* scale_base = (float*)(base + o_scale);
+    size_t soff[32];
+    int rc = fold_scales(L, nl, scale_base, soff, st);
+    if (rc != IRON_OK) return rc;
+
+    HeadSrcs hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.n = 1; hs.slot_base[0] = 0; hs.levels[0] = d.multires; hs.col_off[0] = 0;
+    // layer 0
+    launch_pack_head(base + o_pe0, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
+    launch_pack_bias(base + o_bias, L[0].bias, 0, L[0].out_dim, st);
+    // hidden layers 1..nl-2
+    for (int l = 1; l <= nl - 2; ++l) {
+        const bool is_skip = (l == skip);
+        const float mul = is_skip ? kInvSqrt2 : 1.0f;
+        const int cols_valid = is_skip ? kHidden - pe : kHidden;
+        launch_pack_hidden(base + o_hid + (size_t)(l - 1) * kF4PerHidLayer,
+                           make_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), 0, cols_valid, st);
+        launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, L[l].out_dim, st);
+        if (is_skip) {
+            HeadSrcs h2 = hs;
+            h2.col_off[0] = kHidden - pe;
+            launch_pack_head(base + o_pes, make_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, nq, st);
+        }
+    }
+    // last layer: row 0 = sdf, rows 1.. = feature
+    const iron_linear& last = L[nl - 1];
+    launch_pack_row(base + o_last, make_src(last, scale_base + soff[nl - 1], 1, 0, 1.0f), 0, 0, kHidden, st);
+    if (d.d_out == kHidden + 1) {
+        launch_pack_hidden(base + o_feat, make_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), 0, kHidden, st);
+        launch_pack_bias(base + o_bfeat, last.bias, 1, kHidden, st);
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    float b_last = 0.0f;
+    IRON_HIP_TRY(hipMemcpyAsync(&b_last, last.bias, sizeof(float), hipMemcpyDeviceToHost, st));
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+
+    SdfNetDev& s = net->sdf;
+    s.blob = net->blob;
+    s.blob_bytes = (uint32_t)net->blob_bytes;
+    s.w_pe0 = (uint32_t)(o_pe0 * 16);
+    s.w_hid = (uint32_t)(o_hid * 16);
+    s.w_pe_skip = (uint32_t)(o_pes * 16);
+    s.bias = (uint32_t)(o_bias * 16);
+    s.w_last = (uint32_t)(o_last * 16);
+    s.w_feat = (d.d_out == kHidden + 1) ? (uint32_t)(o_feat * 16) : 0u;
+    s.b_feat = (uint32_t)(o_bfeat * 16);
+    s.b_last = b_last;
+    s.scale = d.scale;
+    s.n_hidden_layers = nl - 1;
+    s.skip_layer = skip;
+    return IRON_OK;
+}
+
+int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int nl = d.n_linear;
+    if (d.d_hidden != kHidden || d.d_feature != kHidden || nl < 2 || nl > 17) return IRON_ERR_UNSUPPORTED;
+    if (d.skip_layer != -1) return IRON_ERR_UNSUPPORTED;  // upstream 8-layer skip variant: not built yet
+    if (d.d_out < 1 || d.d_out > 3) return IRON_ERR_UNSUPPORTED;
+
+    RenderNetDev& r = net->rnd;
+    memset(&r, 0, sizeof(r));
+    HeadSrcs hs;
+    memset(&hs, 0, sizeof(hs));
+    const int lv_p = d.multires > 0 ? d.multires : 0;
+    const int lv_v = d.multires_view > 0 ? d.multires_view : 0;
+    auto add_src = [&](int kind, int levels, int& slot, int& col) {
+        const int k = hs.n++;
+        hs.slot_base[k] = slot; hs.levels[k] = levels; hs.col_off[k] = col;
+        r.src_kind[k] = kind; r.src_levels[k] = levels;
+        slot += head_slots(levels);
+        col += pe_width(levels);
+    };
+    int slot = 0, col = 0;
+    switch (d.mode) {  // input order: models/fields.py:213-220
+        case IRON_MODE_IDR: add_src(0, lv_p, slot, col); add_src(1, lv_v, slot, col); add_src(2, 0, slot, col); break;
+        case IRON_MODE_NO_VIEW_DIR: add_src(0, lv_p, slot, col); add_src(2, 0, slot, col); break;
+        case IRON_MODE_NO_NORMAL: add_src(0, lv_p, slot, col); add_src(1, lv_v, slot, col); break;
+        case IRON_MODE_POINTS_ONLY: add_src(0, lv_p, slot, col); break;
+        default: return IRON_ERR_UNSUPPORTED;
+    }
+    r.n_src = hs.n;
+    const int head_w = col;
+    int nq;
+    if (slot <= 20) nq = 5; else if (slot <= 24) nq = 6; else return IRON_ERR_UNSUPPORTED;
+    for (int l = 0; l < nl; ++l) {
+        if (!L[l].weight_v || !L[l].bias) return IRON_ERR_BAD_ARG;
+        const int want_in = (l == 0) ? head_w + d.d_feature : kHidden;
+        const int want_out = (l == nl - 1) ? d.d_out : kHidden;
+        if (L[l].in_dim != want_in || L[l].out_dim != want_out) return IRON_ERR_UNSUPPORTED;
+    }
+    Blob b;
+    b.take(16);
+    const size_t o_head = b.take((size_t)kPairs * nq * 2 * 64);
+    const size_t o_feat0 = b.take(kF4PerHidLayer);
+    const size_t o_hid = b.take((size_t)(nl - 2) * kF4PerHidLayer);
+    const size_t o_bias = b.take((size_t)(nl - 1) * kF4PerBiasLayer);
+    const size_t o_last = b.take(3 * kF4PerBiasLayer);
+    size_t n_scale = 0;
+    for (int l = 0; l < nl; ++l) n_scale += (size_t)L[l].out_dim;
+    const size_t o_scale = b.take((n_scale + 3) / 4);
+    net->blob_bytes = b.n_f4 * sizeof(float4);
+    IRON_HIP_TRY(hipMalloc(&net->blob, net->blob_bytes));
+    IRON_HIP_TRY(hipMemsetAsync(net->blob, 0, net->blob_bytes, st));
+    float4* base = (float4*)net->blob;
+    float* scale_base = (float*)(base + o_scale);
+    size_t soff[32];
+    int rc = fold_scales(L, nl, scale_base, soff, st);
+    if (rc != IRON_OK) return rc;
+
+    launch_pack_head(base + o_head, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
+    launch_pack_hidden(base + o_feat0, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), head_w, kHidden, st);
+    launch_pack_bias(base + o_bias, L[0].bias, 0, kHidden, st);
+    for (int l = 1; l <= nl - 2; ++l) {
+        launch_pack_hidden(base + o_hid + (size_t)(l - 1) * kF4PerHidLayer,
+                           make_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), 0, kHidden, st);
+        launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, kHidden, st);
+    }
+    const iron_linear& last = L[nl - 1];
+    for (int o = 0; o < d.d_out; ++o)
+        launch_pack_row(base + o_last + (size_t)o * kF4PerBiasLayer, make_src(last, scale_base + soff[nl - 1], d.d_out, 0, 1.0f),
+                        o, 0, kHidden, st);
+    IRON_HIP_TRY(hipGetLastError());
+    float bl[3] = {0, 0, 0};
+    IRON_HIP_TRY(hipMemcpyAsync(bl, last.bias, sizeof(float) * d.d_out, hipMemcpyDeviceToHost, st));
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+
+    r.blob = net->blob;
+    r.blob_bytes = (uint32_t)net->blob_bytes;
+    r.w_head0 = (uint32_t)(o_head * 16);
+    r.w_feat0 = (uint32_t)(o_feat0 * 16);
+    r.w_hid = (uint32_t)(o_hid * 16);
+    r.bias = (uint32_t)(o_bias * 16);
+    r.w_last = (uint32_t)(o_last * 16);
+    for (int o = 0; o < 3; ++o) r.b_last[o] = bl[o];
+    r.d_out = d.d_out;
+    r.n_hidden_layers = nl - 1;
+    r.head_quads = nq;
+    r.squeeze_out = d.squeeze_out;
+    r.squeeze_out_scale = d.squeeze_out_scale;
+    r.output_bias = d.output_bias;
+    r.output_scale = d.output_scale;
+    return IRON_OK;
+}
+
+}  // namespace
+
+extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, const iron_linear* layers, void* stream) {
+    if (!out || !desc || !layers) return IRON_ERR_BAD_ARG;
+    *out = nullptr;
+    int dev = 0;
+    int rc = check_device(&dev);
+    if (rc != IRON_OK) return rc;
+    iron_net* net = new (std::nothrow) iron_net();
+    if (!net) return IRON_ERR_BAD_ARG;
+    memset(net, 0, sizeof(*net));
+    net->desc = *desc;
+    net->device = dev;
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->kind == IRON_NET_SDF) rc = create_sdf(net, layers, st);
+    else if (desc->kind == IRON_NET_RENDER) rc = create_render(net, layers, st);
+    else rc = IRON_ERR_UNSUPPORTED;
+    if (rc != IRON_OK) {
+        if (net->blob) (void)hipFree(net->blob);
+        delete net;
+        return rc;
+    }
+    *out = net;
+    return IRON_OK;
+}
+
+extern "C" int iron_net_destroy(iron_net_t* net) {
+    if (!net) return IRON_OK;
+    if (net->blob) IRON_HIP_TRY(hipFree(net->blob));
+    delete net;
+    return IRON_OK;
+}

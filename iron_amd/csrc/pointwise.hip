@@ -1,0 +1,119 @@
+// HBM-bound pointwise entry points: camera rays, unit-sphere intersection, standalone GGX.
+#include "iron_common.h"
+#include "ggx_core.h"
+
+namespace iron {
+
+struct CamMat {
+    float kinv[9];
+    float c2w[12];
+};
+
+// Camera.get_rays (models/raytracer.py:254-286)
+__global__ void k_camera_rays(CamMat m, const float* __restrict__ uv, int64_t n, float* __restrict__ ray_o,
+                              float* __restrict__ ray_d, float* __restrict__ ray_d_norm) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float u = uv[2 * i], v = uv[2 * i + 1];
+        float c[3], w[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) c[r] = fmaf(1.0f, m.kinv[3 * r + 2], fmaf(v, m.kinv[3 * r + 1], u * m.kinv[3 * r]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            w[r] = fmaf(c[2], m.c2w[4 * r + 2], fmaf(c[1], m.c2w[4 * r + 1], c[0] * m.c2w[4 * r]));
+        const float nrm = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+        ray_d[3 * i] = w[0] / nrm;
+        ray_d[3 * i + 1] = w[1] / nrm;
+        ray_d[3 * i + 2] = w[2] / nrm;
+        ray_d_norm[i] = nrm;
+        ray_o[3 * i] = m.c2w[3];
+        ray_o[3 * i + 1] = m.c2w[7];
+        ray_o[3 * i + 2] = m.c2w[11];
+    }
+}
+
+__global__ void k_intersect_sphere(const float* __restrict__ ray_o, const float* __restrict__ ray_d, int64_t n,
+                                   float r, uint8_t* __restrict__ mask, float* __restrict__ near,
+                                   float* __restrict__ far) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float o[3] = {ray_o[3 * i], ray_o[3 * i + 1], ray_o[3 * i + 2]};
+        const float d[3] = {ray_d[3 * i], ray_d[3 * i + 1], ray_d[3 * i + 2]};
+        bool hit;
+        float a, b;
+        intersect_sphere_ray(o, d, r, hit, a, b);
+        mask[i] = hit ? 1 : 0;
+        near[i] = a;
+        far[i] = b;
+    }
+}
+
+__global__ void k_ggx(float light, const float* __restrict__ distance, const float* __restrict__ normal,
+                      const float* __restrict__ viewdir, const float* __restrict__ kd, const float* __restrict__ ks,
+                      const float* __restrict__ rough, const float* __restrict__ tab_trans,
+                      const float* __restrict__ tab_diff, int64_t n, float* __restrict__ diffuse_rgb,
+                      float* __restrict__ specular_rgb, float* __restrict__ rgb) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float nn[3] = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+        const float vv[3] = {viewdir[3 * i], viewdir[3 * i + 1], viewdir[3 * i + 2]};
+        const float a[3] = {kd[3 * i], kd[3 * i + 1], kd[3 * i + 2]};
+        const float s[3] = {ks[3 * i], ks[3 * i + 1], ks[3 * i + 2]};
+        GgxOut o;
+        ggx_colocated_point(light, distance[i], nn, vv, a, s, rough[i], tab_trans, tab_diff, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (diffuse_rgb) diffuse_rgb[3 * i + c] = o.diffuse[c];
+            if (specular_rgb) specular_rgb[3 * i + c] = o.specular[c];
+            if (rgb) rgb[3 * i + c] = o.rgb[c];
+        }
+    }
+}
+
+static inline int pw_grid(int64_t n) {
+    const int64_t b = (n + 255) / 256;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+}  // namespace iron
+
+using namespace iron;
+
+extern "C" int iron_camera_rays(const float* k_inv3, const float* c2w34, const float* uv, int64_t n, float* ray_o,
+                                float* ray_d, float* ray_d_norm, void* stream) {
+    if (!k_inv3 || !c2w34 || n < 0 || (n > 0 && (!uv || !ray_o || !ray_d || !ray_d_norm))) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    CamMat m;
+    for (int i = 0; i < 9; ++i) m.kinv[i] = k_inv3[i];
+    for (int i = 0; i < 12; ++i) m.c2w[i] = c2w34[i];
+    hipLaunchKernelGGL(k_camera_rays, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, m, uv, n, ray_o, ray_d,
+                       ray_d_norm);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_intersect_sphere(const float* ray_o, const float* ray_d, int64_t n, float r, uint8_t* mask,
+                                     float* near, float* far, void* stream) {
+    if (n < 0 || (n > 0 && (!ray_o || !ray_d || !mask || !near || !far))) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    hipLaunchKernelGGL(k_intersect_sphere, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, n, r,
+                       mask, near, far);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_ggx_colocated(float light, const float* distance, const float* normal, const float* viewdir,
+                                  const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                                  const float* tab_trans, const float* tab_diff_trans, int64_t n, float* diffuse_rgb,
+                                  float* specular_rgb, float* rgb, void* stream) {
+    if (n < 0) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!distance || !normal || !viewdir || !diffuse_albedo || !specular_albedo || !roughness || !tab_trans ||
+        !tab_diff_trans)
+        return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_ggx, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, light, distance, normal, viewdir,
+                       diffuse_albedo, specular_albedo, roughness, tab_trans, tab_diff_trans, n, diffuse_rgb,
+                       specular_rgb, rgb);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}

@@ -1,0 +1,279 @@
+"""SDFNetwork / RenderingNetwork with the reference's constructor and method surface
+(models/fields.py:9-137, 141-239), forward passes routed to the gfx950 HIP kernels.
+
+Parameters live in torch exactly as in the reference (`lin{l}.weight_g [out,1]`, `lin{l}.weight_v
+[out,in]`, `lin{l}.bias`; old-style weight_norm, fields.py:75-76), so reference checkpoints load
+with `load_state_dict`.  The HIP side keeps a packed copy (weight norm folded, MFMA fragment order)
+that is rebuilt whenever a parameter's version counter changes.
+
+There is no CPU / eager compute path here: tensors must be CUDA (ROCm) fp32.
+Only inference is built (autograd through the kernels is a later row).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .embedder import get_embedder
+
+
+class _Linear(nn.Module):
+    """One (optionally weight-normed) linear layer's parameters, named like the reference's."""
+
+    def __init__(self, lin: nn.Linear, weight_norm: bool):
+        super().__init__()
+        self.in_features, self.out_features = lin.in_features, lin.out_features
+        self.has_weight_norm = weight_norm
+        w = lin.weight.data
+        if weight_norm:
+            # nn.utils.weight_norm(dim=0): g = ||v||_row [out,1], v = w
+            self.weight_g = nn.Parameter(torch.norm_except_dim(w, 2, 0).data)
+            self.weight_v = nn.Parameter(w.clone())
+        else:
+            self.weight = nn.Parameter(w.clone())
+        self.bias = nn.Parameter(lin.bias.data.clone())
+
+    def effective_weight(self) -> torch.Tensor:
+        if self.has_weight_norm:
+            return torch._weight_norm(self.weight_v, self.weight_g, 0)
+        return self.weight
+
+
+class _NetHandle:
+    """Owns an iron_net_t*."""
+
+    def __init__(self, handle: int, device: torch.device):
+        self.handle = handle
+        self.device = device
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().iron_net_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = 0
+
+
+class _HipNet(nn.Module):
+    """Shared packing/caching logic."""
+
+    _kind = _lib.IRON_NET_SDF
+
+    def _layers(self):
+        return [getattr(self, "lin%d" % l) for l in range(self.num_layers - 1)]
+
+    def _desc(self) -> _lib.iron_net_desc:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+
+    def hip_net(self) -> _NetHandle:
+        """The packed device copy of the current parameters (rebuilt if they changed)."""
+        key = self._param_key()
+        cached = self.__dict__.get("_hip_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        layers = self._layers()
+        dev = layers[0].bias.device
+        if dev.type != "cuda":
+            raise _lib.IronError("network parameters must live on a CUDA (ROCm) device; call .cuda() first")
+        lib = _lib.load()
+        arr = (_lib.iron_linear * len(layers))()
+        keep = []
+        for i, lin in enumerate(layers):
+            if lin.has_weight_norm:
+                v = lin.weight_v.detach().float().contiguous()
+                g = lin.weight_g.detach().float().contiguous().view(-1)
+                keep += [v, g]
+                arr[i].weight_v, arr[i].weight_g = v.data_ptr(), g.data_ptr()
+            else:
+                v = lin.weight.detach().float().contiguous()
+                keep.append(v)
+                arr[i].weight_v, arr[i].weight_g = v.data_ptr(), None
+            b = lin.bias.detach().float().contiguous()
+            keep.append(b)
+            arr[i].bias = b.data_ptr()
+            arr[i].out_dim, arr[i].in_dim = lin.out_features, lin.in_features
+        desc = self._desc()
+        out = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.iron_net_create(C.byref(out), C.byref(desc), arr, _lib.stream_ptr(dev)))
+        handle = _NetHandle(out.value, dev)
+        self.__dict__["_hip_cache"] = (key, handle)
+        return handle
+
+
+# IDR-style SDF MLP (reference: models/fields.py:9-137)
+class SDFNetwork(_HipNet):
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1,
+                 geometric_init=True, weight_norm=True, inside_outside=False):
+        super().__init__()
+        dims = [d_in] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.embed_fn_fine = None
+        self.multires = multires
+        if multires > 0:
+            embed_fn, input_ch = get_embedder(multires, input_dims=d_in)
+            self.embed_fn_fine = embed_fn
+            dims[0] = input_ch
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        self.d_in, self.d_out, self.d_hidden = d_in, d_out, d_hidden
+
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)  # default init first: keeps the RNG stream of the reference
+            if geometric_init:  # SAL/IDR geometric initialisation (fields.py:47-73): a sphere of radius `bias`
+                if l == self.num_layers - 2:
+                    mean = np.sqrt(np.pi) / np.sqrt(dims[l])
+                    if not inside_outside:
+                        torch.nn.init.normal_(lin.weight, mean=mean, std=0.0001)
+                        torch.nn.init.constant_(lin.bias, -bias)
+                    else:
+                        torch.nn.init.normal_(lin.weight, mean=-mean, std=0.0001)
+                        torch.nn.init.constant_(lin.bias, bias)
+                elif multires > 0 and l == 0:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif multires > 0 and l in self.skip_in:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            setattr(self, "lin" + str(l), _Linear(lin, weight_norm))
+
+    def _desc(self) -> _lib.iron_net_desc:
+        d = _lib.iron_net_desc()
+        d.kind = _lib.IRON_NET_SDF
+        d.n_linear = self.num_layers - 1
+        d.d_hidden = self.d_hidden
+        d.d_out = self.d_out
+        d.multires = self.multires
+        d.multires_view = 0
+        if len(self.skip_in) > 1 or self.d_in != 3:
+            raise _lib.IronError("unsupported SDFNetwork shape for the gfx950 kernels")
+        d.skip_layer = self.skip_in[0] if self.skip_in else -1
+        d.scale = float(self.scale)
+        return d
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """[..., 3] -> [..., d_out]  (fields.py:82-98)."""
+        return self._run(inputs, self.d_out)
+
+    def _run(self, inputs: torch.Tensor, out_cols: int) -> torch.Tensor:
+        x = _lib.require_cuda_f32(inputs.detach(), "inputs")
+        sh = list(x.shape[:-1])
+        x = x.reshape(-1, 3)
+        net = self.hip_net()
+        out = torch.empty((x.shape[0], out_cols), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().iron_sdf_forward(net.handle, x.data_ptr(), x.shape[0], out.data_ptr(), out_cols,
+                                                    _lib.stream_ptr(x.device)))
+        return out.reshape(sh + [out_cols])
+
+    def sdf(self, x: torch.Tensor) -> torch.Tensor:
+        """fields.py:100-101: [..., 1]; uses the sdf-only kernel (no 256-wide feature epilogue)."""
+        return self._run(x, 1)
+
+    def sdf_hidden_appearance(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward(x)
+
+    def gradient(self, x: torch.Tensor) -> torch.Tensor:
+        """d sdf / dx (fields.py:106-118), value only: no autograd graph is attached."""
+        return self.get_all(x, is_training=False)[2]
+
+    def get_all(self, x: torch.Tensor, is_training: bool = True):
+        """sdf [...,1], feature [...,d_out-1], gradient [...,3]  (fields.py:120-137)."""
+        if is_training:
+            raise NotImplementedError("iron_amd builds the forward render path only (is_training=False); "
+                                      "autograd through the HIP kernels is SURVEY 8 row f-2")
+        xx = _lib.require_cuda_f32(x.detach(), "x")
+        sh = list(xx.shape[:-1])
+        xx = xx.reshape(-1, 3)
+        n = xx.shape[0]
+        net = self.hip_net()
+        sdf = torch.empty((n, 1), dtype=torch.float32, device=xx.device)
+        feat = torch.empty((n, self.d_out - 1), dtype=torch.float32, device=xx.device)
+        grad = torch.empty((n, 3), dtype=torch.float32, device=xx.device)
+        with torch.cuda.device(xx.device):
+            _lib.check(_lib.load().iron_sdf_get_all(net.handle, xx.data_ptr(), n, sdf.data_ptr(), feat.data_ptr(),
+                                                    grad.data_ptr(), _lib.stream_ptr(xx.device)))
+        return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])
+
+
+# IDR-style material MLP (reference: models/fields.py:141-239)
+class RenderingNetwork(_HipNet):
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires=0,
+                 multires_view=0, squeeze_out=True, squeeze_out_scale=1.0, output_bias=0.0, output_scale=1.0,
+                 skip_in=()):
+        super().__init__()
+        self.mode = mode
+        self.squeeze_out = squeeze_out
+        self.d_feature, self.d_out, self.d_hidden = d_feature, d_out, d_hidden
+        self.multires, self.multires_view = multires, multires_view
+        dims = [d_in + d_feature] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.embed_fn = None
+        if multires > 0:
+            self.embed_fn, input_ch = get_embedder(multires)
+            dims[0] += input_ch - 3
+        self.embedview_fn = None
+        if multires_view > 0:
+            self.embedview_fn, input_ch = get_embedder(multires_view)
+            dims[0] += input_ch - 3
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                dims[l] += dims[0]
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            setattr(self, "lin" + str(l), _Linear(nn.Linear(dims[l], out_dim), weight_norm))
+        self.output_bias = output_bias
+        self.output_scale = output_scale
+        self.squeeze_out_scale = squeeze_out_scale
+
+    def _desc(self) -> _lib.iron_net_desc:
+        d = _lib.iron_net_desc()
+        d.kind = _lib.IRON_NET_RENDER
+        d.n_linear = self.num_layers - 1
+        d.d_hidden = self.d_hidden
+        d.d_out = self.d_out
+        d.multires = self.multires
+        d.multires_view = self.multires_view
+        d.skip_layer = self.skip_in[0] if self.skip_in else -1
+        if len(self.skip_in) > 1:
+            raise _lib.IronError("unsupported RenderingNetwork shape for the gfx950 kernels")
+        d.mode = _lib.MODES[self.mode]
+        d.d_feature = self.d_feature
+        d.squeeze_out = 1 if self.squeeze_out else 0
+        d.squeeze_out_scale = float(self.squeeze_out_scale)
+        d.output_bias = float(self.output_bias)
+        d.output_scale = float(self.output_scale)
+        d.scale = 1.0
+        return d
+
+    def forward(self, points, normals, view_dirs, feature_vectors) -> torch.Tensor:
+        """[...,3] x3 (+ [...,d_feature]) -> [..., d_out]  (fields.py:203-239)."""
+        p = _lib.require_cuda_f32(points.detach(), "points")
+        sh = list(p.shape[:-1])
+        p = p.reshape(-1, 3)
+        n = p.shape[0]
+        nrm = _lib.require_cuda_f32(normals.detach(), "normals").reshape(-1, 3) if normals is not None else None
+        vd = _lib.require_cuda_f32(view_dirs.detach(), "view_dirs").reshape(-1, 3) if view_dirs is not None else None
+        ft = _lib.require_cuda_f32(feature_vectors.detach(), "feature_vectors").reshape(-1, self.d_feature)
+        net = self.hip_net()
+        out = torch.empty((n, self.d_out), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.load().iron_render_forward(net.handle, p.data_ptr(), _lib.ptr(nrm), _lib.ptr(vd),
+                                                       ft.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(p.device)))
+        return out.reshape(sh + [self.d_out])

@@ -1,0 +1,69 @@
+"""Synthetic scenes / cameras for tests and bench: no dataset or checkpoint exists
+offline, so the "drv/dragon" configs are restated as seeded networks.
+
+S0 "sphere": seed 0, geometric init (SDF ~ sphere r 0.5), `ggx` material nets, light 8*2^2 = 32
+              (render_surface.py:353-355 rule at camera distance 2).
+S1 "bumpy" : S0 + N(0, 0.01^2) on lin0.weight_v[:, 3:] (seed 1) so PE channels shape the surface
+              (SURVEY proposed sigma 0.05, which leaves no zero level set; 0.01 gives ~34 % hits).
+Cameras    : the reference fixture camera (tests/data_singleview/cam_dict_norm.json) rescaled.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .network_conf import PointLightNetwork
+from .fields import RenderingNetwork, SDFNetwork
+
+# tests/data_singleview/cam_dict_norm.json of the reference (512x512)
+FIXTURE_K = [[811.9282694049824, 0.0, 256.0, 0.0], [0.0, 811.9282694049824, 256.0, 0.0],
+             [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+FIXTURE_W2C = [[0.998867339183008, 0.0, -0.04758191582374219, 1.5416074755814572e-17],
+               [-0.013163727354886733, -0.9609695958324571, -0.27634064516051604, 1.1553154537250536e-16],
+               [-0.045724774418075535, 0.27665400030652737, -0.959881143224937, 2.0],
+               [0.0, 0.0, 0.0, 1.0]]
+FIXTURE_SIZE = 512
+
+
+def build_networks(scene: str = "S0", seed: int = 0) -> Dict[str, torch.nn.Module]:
+    """CPU-resident networks; construction order fixes the RNG stream (sdf, diffuse, specular, roughness)."""
+    torch.manual_seed(seed)
+    nets = {
+        "sdf_network": SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
+                                  scale=1.0, geometric_init=True, weight_norm=True),
+        "diffuse_albedo_network": RenderingNetwork(d_in=9, d_out=3, d_feature=256, d_hidden=256, n_layers=4,
+                                                   multires_view=4, mode="idr", squeeze_out=True),
+        "specular_albedo_network": RenderingNetwork(d_in=6, d_out=3, d_feature=256, d_hidden=256, n_layers=4,
+                                                    multires=6, multires_view=-1, mode="no_view_dir",
+                                                    squeeze_out=False, output_bias=0.4, output_scale=0.1),
+        "specular_roughness_network": RenderingNetwork(d_in=6, d_out=1, d_feature=256, d_hidden=256, n_layers=4,
+                                                       multires=6, multires_view=-1, mode="no_view_dir",
+                                                       squeeze_out=False, output_bias=0.1, output_scale=0.1),
+        "point_light_network": PointLightNetwork(),
+    }
+    nets["point_light_network"].set_light(8.0 * 2.0 * 2.0)
+    if scene == "S1":
+        g = torch.Generator().manual_seed(1)
+        v = nets["sdf_network"].lin0.weight_v
+        with torch.no_grad():
+            v[:, 3:] += 0.01 * torch.randn(v[:, 3:].shape, generator=g)
+    elif scene != "S0":
+        raise ValueError(scene)
+    return nets
+
+
+def fixture_camera_matrices(width: int, height: int, yaw_deg: float = 0.0):
+    """K, W2C (4x4 fp32) of the fixture camera rescaled to width x height, optionally orbited about
+    world Y by yaw_deg (C4's 8 views = k*45 degrees)."""
+    K = torch.tensor(FIXTURE_K, dtype=torch.float32)
+    K[0, :3] *= width / FIXTURE_SIZE
+    K[1, :3] *= height / FIXTURE_SIZE
+    W2C = torch.tensor(FIXTURE_W2C, dtype=torch.float64)
+    if yaw_deg != 0.0:
+        a = math.radians(yaw_deg)
+        R = torch.tensor([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0],
+                          [0, 0, 0, 1]], dtype=torch.float64)
+        W2C = W2C @ R
+    return K, W2C.float()

@@ -1,0 +1,534 @@
+"""CPU oracle for IRON's stage-2 forward render path (TEST INFRASTRUCTURE ONLY).
+
+This file is a from-scratch torch-CPU restatement of the reference algorithm
+for the hot path named in BASELINE.json: positional encoding, the weight-normed
+SDF / material MLPs, unit-sphere intersection, camera ray generation, the
+sphere tracer (sphere tracing -> dense sampler -> bisection), material query,
+the co-located GGX BRDF and the render_camera assembly.
+
+It is the checker, never the product: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it.  The shipped path is
+iron_amd/ (HIP kernels behind the C ABI) and never routes through here.
+
+Parity pin: tests/golden/*.npz were generated in the build container by
+tests/golden/make_golden.py, which imports the real reference from
+/root/reference and records its outputs; tests/test_oracle_golden.py checks
+every function below against those vectors.  The op sequence is kept
+op-for-op equivalent to the reference (separate mul/add, same torch kernels),
+so on the same torch build the outputs are bit-identical.
+
+Each function cites the reference file:line it restates (paths relative to the
+reference root).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------
+# positional encoding -- models/embedder.py:6-54
+# ----------------------------------------------------------------------------
+def positional_encoding(x: Tensor, n_freqs: int) -> Tensor:
+    """[..., d] -> [..., d + 2*d*n_freqs]: cat[x, sin(x*2^0), cos(x*2^0), ...].
+
+    models/embedder.py:22-36: freq bands are 2**linspace(0, L-1, L) (fp32
+    0-dim tensors), each term is p_fn(x * freq).  n_freqs <= 0 -> identity.
+    """
+    if n_freqs <= 0:
+        return x
+    bands = 2.0 ** torch.linspace(0.0, float(n_freqs - 1), n_freqs)
+    parts = [x]
+    for fr in bands:
+        parts.append(torch.sin(x * fr))
+        parts.append(torch.cos(x * fr))
+    return torch.cat(parts, dim=-1)
+
+
+def pe_width(n_freqs: int, d: int = 3) -> int:
+    return d if n_freqs <= 0 else d + 2 * d * n_freqs
+
+
+# ----------------------------------------------------------------------------
+# network descriptions (plain data; weights are a state_dict of CPU tensors)
+# ----------------------------------------------------------------------------
+@dataclass
+class SDFSpec:
+    """models/fields.py:9-45 constructor arguments that shape the forward."""
+    d_in: int = 3
+    d_out: int = 257
+    d_hidden: int = 256
+    n_layers: int = 8
+    skip_in: Tuple[int, ...] = (4,)
+    multires: int = 6
+    scale: float = 1.0
+
+    @property
+    def n_linear(self) -> int:
+        return self.n_layers + 1
+
+
+@dataclass
+class RenderSpec:
+    """models/fields.py:141-201 constructor arguments that shape the forward."""
+    d_feature: int = 256
+    mode: str = "idr"
+    d_in: int = 9
+    d_out: int = 3
+    d_hidden: int = 256
+    n_layers: int = 4
+    multires: int = 0
+    multires_view: int = 0
+    squeeze_out: bool = True
+    squeeze_out_scale: float = 1.0
+    output_bias: float = 0.0
+    output_scale: float = 1.0
+    skip_in: Tuple[int, ...] = ()
+
+    @property
+    def n_linear(self) -> int:
+        return self.n_layers + 1
+
+
+# the `ggx` branch of models/network_conf.py:48-122
+GGX_SPECS: Dict[str, RenderSpec] = {
+    "diffuse_albedo_network": RenderSpec(d_in=9, d_out=3, n_layers=4, multires_view=4, mode="idr", squeeze_out=True),
+    "specular_albedo_network": RenderSpec(
+        d_in=6, d_out=3, n_layers=4, multires=6, multires_view=-1, mode="no_view_dir",
+        squeeze_out=False, output_bias=0.4, output_scale=0.1),
+    "specular_roughness_network": RenderSpec(
+        d_in=6, d_out=1, n_layers=4, multires=6, multires_view=-1, mode="no_view_dir",
+        squeeze_out=False, output_bias=0.1, output_scale=0.1),
+}
+
+
+def effective_weight(sd: Dict[str, Tensor], l: int) -> Tuple[Tensor, Tensor]:
+    """Old-style weight_norm(dim=0) folding: W = v * (g / ||v||_row).
+
+    models/fields.py:75-76 (nn.utils.weight_norm) -> torch._weight_norm(v, g, 0).
+    Plain (un-normed) layers carry `lin{l}.weight`.
+    """
+    key = "lin%d." % l
+    if key + "weight_v" in sd:
+        w = torch._weight_norm(sd[key + "weight_v"], sd[key + "weight_g"], 0)
+    else:
+        w = sd[key + "weight"]
+    return w, sd[key + "bias"]
+
+
+def softplus100(x: Tensor) -> Tensor:
+    """nn.Softplus(beta=100) with torch's default threshold 20 (fields.py:80)."""
+    return F.softplus(x, beta=100.0, threshold=20.0)
+
+
+# ----------------------------------------------------------------------------
+# SDF network -- models/fields.py:82-137
+# ----------------------------------------------------------------------------
+class EvalCounter:
+    """Counts SDF point evaluations (SURVEY 8d's E) made through `sdf_fn`."""
+
+    def __init__(self):
+        self.evals = 0
+
+
+def sdf_forward(sd: Dict[str, Tensor], spec: SDFSpec, x: Tensor) -> Tensor:
+    """[M,3] -> [M,d_out]; column 0 is the signed distance (fields.py:82-98)."""
+    inputs = x * spec.scale
+    if spec.multires > 0:
+        inputs = positional_encoding(inputs, spec.multires)
+    h = inputs
+    for l in range(spec.n_linear):
+        w, b = effective_weight(sd, l)
+        if l in spec.skip_in:
+            h = torch.cat([h, inputs], dim=-1) / np.sqrt(2)
+        h = F.linear(h, w, b)
+        if l < spec.n_linear - 1:
+            h = softplus100(h)
+    return torch.cat([h[..., :1] / spec.scale, h[..., 1:]], dim=-1)
+
+
+def sdf_get_all(sd: Dict[str, Tensor], spec: SDFSpec, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """sdf [M,1], feature [M,d_out-1], d sdf/dx [M,3] (fields.py:120-137, is_training=False)."""
+    with torch.enable_grad():
+        xg = x.detach().clone().requires_grad_(True)
+        out = sdf_forward(sd, spec, xg)
+        y, feat = out[..., :1], out[..., 1:]
+        (grad,) = torch.autograd.grad(y, xg, torch.ones_like(y), create_graph=False, retain_graph=False)
+    return y.detach(), feat.detach(), grad.detach()
+
+
+# ----------------------------------------------------------------------------
+# material ("rendering") network -- models/fields.py:203-239
+# ----------------------------------------------------------------------------
+def rendering_forward(sd: Dict[str, Tensor], spec: RenderSpec, points: Tensor, normals: Tensor,
+                      view_dirs: Optional[Tensor], feats: Tensor) -> Tensor:
+    if spec.multires > 0:
+        points = positional_encoding(points, spec.multires)
+    if spec.multires_view > 0 and spec.mode not in ("no_view_dir", "points_only"):
+        view_dirs = positional_encoding(view_dirs, spec.multires_view)
+    if spec.mode == "idr":
+        inp = torch.cat([points, view_dirs, normals, feats], dim=-1)
+    elif spec.mode == "no_view_dir":
+        inp = torch.cat([points, normals, feats], dim=-1)
+    elif spec.mode == "no_normal":
+        inp = torch.cat([points, view_dirs, feats], dim=-1)
+    elif spec.mode == "points_only":
+        inp = torch.cat([points, feats], dim=-1)
+    else:
+        raise ValueError(spec.mode)
+    h = inp
+    for l in range(spec.n_linear):
+        w, b = effective_weight(sd, l)
+        if l in spec.skip_in:
+            h = torch.cat([h, inp], dim=-1) / np.sqrt(2)
+        h = F.linear(h, w, b)
+        if l < spec.n_linear - 1:
+            h = torch.relu(h)
+    h = spec.output_scale * (h + spec.output_bias)
+    if spec.squeeze_out:
+        h = spec.squeeze_out_scale * torch.sigmoid(h)
+    return h
+
+
+def get_materials(nets: Dict[str, Tuple[Dict[str, Tensor], RenderSpec]], points: Tensor, normals: Tensor,
+                  feats: Tensor, is_metal: bool = False) -> Dict[str, Tensor]:
+    """models/rendering_func.py:5-16."""
+    sd, sp = nets["diffuse_albedo_network"]
+    diffuse = rendering_forward(sd, sp, points, normals, -normals, feats).abs()
+    sd, sp = nets["specular_albedo_network"]
+    spec = rendering_forward(sd, sp, points, normals, None, feats).abs()
+    if not is_metal:
+        spec = torch.mean(spec, dim=-1, keepdim=True).expand_as(spec)
+    sd, sp = nets["specular_roughness_network"]
+    rough = rendering_forward(sd, sp, points, normals, None, feats).abs() + 0.01
+    return {"diffuse_albedo": diffuse, "specular_albedo": spec, "specular_roughness": rough}
+
+
+# ----------------------------------------------------------------------------
+# co-located GGX -- models/renderer_ggx.py:12-16, 61-146
+# ----------------------------------------------------------------------------
+def smith_g1(cos_theta: Tensor, alpha: Tensor) -> Tensor:
+    sin_theta = torch.sqrt(1.0 - cos_theta * cos_theta)
+    tan_theta = sin_theta / (cos_theta + 1e-10)
+    root = alpha * tan_theta
+    return 2.0 / (1.0 + torch.hypot(root, torch.ones_like(root)))
+
+
+def ggx_colocated(light, distance: Tensor, normal: Tensor, viewdir: Tensor, params: Dict[str, Tensor],
+                  mts_trans: Tensor, mts_diff_trans: Tensor) -> Dict[str, Tensor]:
+    """renderer_ggx.py:82-146.  mts_trans: 5000 floats, mts_diff_trans: 50 floats."""
+    kd, ks, alpha = params["diffuse_albedo"], params["specular_albedo"], params["specular_roughness"]
+    intensity = light / (distance * distance + 1e-10)
+    dot = torch.sum(viewdir * normal, dim=-1, keepdim=True)
+    dot = torch.clamp(dot, min=0.00001, max=0.99999)
+    m_eta = 1.48958738
+    m_inv_eta2 = 1.0 / (m_eta * m_eta)
+    alpha = torch.clamp(alpha, min=0.0001)
+    c2 = dot * dot
+    root = c2 + (1.0 - c2) / (alpha * alpha + 1e-10)
+    D = 1.0 / (np.pi * alpha * alpha * root * root + 1e-10)
+    Fr = 0.03867
+    G = smith_g1(dot, alpha) ** 2
+    specular = intensity * ks * Fr * D * G / (4.0 * dot + 1e-10)
+
+    n_theta, n_alpha = 100, 50
+    warped_cos = dot ** 0.25
+    warped_alpha = ((alpha - 0) / (4 - 0)) ** 0.25
+    tx = torch.floor(warped_cos * n_theta).long()
+    ty = torch.floor(warped_alpha * n_alpha).long()
+    t_idx = torch.clamp(ty * n_theta + tx, min=0, max=mts_trans.numel() - 1)
+    T12 = torch.clamp(mts_trans[t_idx.squeeze(-1)].unsqueeze(-1), min=0.0, max=1.0)
+    a_idx = torch.clamp(ty, min=0, max=mts_diff_trans.numel() - 1)
+    Fdr = torch.clamp(1.0 - mts_diff_trans[a_idx.squeeze(-1)].unsqueeze(-1), min=0.0, max=1.0)
+    diffuse = intensity * (kd / (1.0 - Fdr + 1e-10) / np.pi) * dot * T12 * T12 * m_inv_eta2
+    return {"diffuse_rgb": diffuse, "specular_rgb": specular, "rgb": diffuse + specular}
+
+
+# ----------------------------------------------------------------------------
+# geometry helpers -- models/raytracer.py:223-303
+# ----------------------------------------------------------------------------
+def intersect_sphere(ray_o: Tensor, ray_d: Tensor, r: float = 1.0) -> Tuple[Tensor, Tensor, Tensor]:
+    """raytracer.py:223-237."""
+    d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+    p = ray_o + d1.unsqueeze(-1) * ray_d
+    tmp = r * r - torch.sum(p * p, dim=-1)
+    mask = tmp > 0.0
+    d2 = torch.sqrt(torch.clamp(tmp, min=0.0)) / torch.norm(ray_d, dim=-1)
+    return mask, torch.clamp(d1 - d2, min=0.0), d1 + d2
+
+
+@dataclass
+class CameraSpec:
+    W: int
+    H: int
+    K: Tensor  # [4,4]
+    W2C: Tensor  # [4,4]
+
+    def __post_init__(self):
+        self.K_inv = torch.inverse(self.K)   # raytracer.py:250
+        self.C2W = torch.inverse(self.W2C)   # raytracer.py:251
+
+    def get_uv(self) -> Tensor:
+        """raytracer.py:300-303: pixel centres, [H,W,2]."""
+        u, v = np.meshgrid(np.arange(self.W), np.arange(self.H))
+        return torch.from_numpy(np.stack((u, v), axis=-1).astype(np.float32)) + 0.5
+
+    def get_rays(self, uv: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """raytracer.py:254-286."""
+        sh = list(uv.shape[:-1])
+        uv = uv.reshape(-1, 2)
+        uv1 = torch.cat((uv, torch.ones_like(uv[..., 0:1])), dim=-1)
+        d = torch.matmul(torch.matmul(uv1, self.K_inv[:3, :3].transpose(1, 0)),
+                         self.C2W[:3, :3].transpose(1, 0)).reshape(sh + [3])
+        dn = d.norm(dim=-1)
+        d = d / dn.unsqueeze(-1)
+        o = self.C2W[:3, 3].unsqueeze(0).expand(uv1.shape[0], -1).reshape(sh + [3])
+        return o, d, dn
+
+    def crop(self, tw: int, th: int, ul: Tuple[int, int]) -> "CameraSpec":
+        """raytracer.py:327-351 with an explicit ul_corner=(col,row)."""
+        K = self.K.clone()
+        K[0, 2] -= ul[0]
+        K[1, 2] -= ul[1]
+        return CameraSpec(tw, th, K, self.W2C.clone())
+
+    def scaled(self, W: int, H: int) -> "CameraSpec":
+        """raytracer.py:353-364 (Camera.resize without the image)."""
+        K = self.K.clone()
+        K[0, :3] *= W / self.W
+        K[1, :3] *= H / self.H
+        return CameraSpec(W, H, K, self.W2C.clone())
+
+
+# ----------------------------------------------------------------------------
+# ray tracer -- models/raytracer.py:27-220
+# ----------------------------------------------------------------------------
+@dataclass
+class TracerParams:
+    sdf_threshold: float = 5.0e-5
+    sphere_tracing_iters: int = 16
+    n_steps: int = 128
+    max_num_pts: int = 200000
+
+
+def sphere_tracing(sdf_fn: Callable[[Tensor], Tensor], ray_o, ray_d, min_dis, max_dis, work_mask,
+                   prm: TracerParams):
+    """raytracer.py:105-140."""
+    iters = 0
+    unfinished = work_mask.clone()
+    t = min_dis.clone()
+    p = ray_o + ray_d * t.unsqueeze(-1)
+    s = sdf_fn(p)
+    while True:
+        unfinished = unfinished & (s.abs() > prm.sdf_threshold) & (t < max_dis)
+        if iters == prm.sphere_tracing_iters or unfinished.sum() == 0:
+            break
+        iters += 1
+        step = s[unfinished]
+        t[unfinished] += step
+        p[unfinished] += ray_d[unfinished] * step.unsqueeze(-1)
+        s[unfinished] = sdf_fn(p[unfinished])
+    conv = work_mask & ~unfinished & (s.abs() <= prm.sdf_threshold) & (t < max_dis)
+    return conv, unfinished, p, s, t
+
+
+def rootfind(sdf_fn, f_low, f_high, d_low, d_high, ray_o, ray_d, prm: TracerParams):
+    """raytracer.py:199-220.  NB every ray is updated each iteration; the loop runs while ANY
+    initially bracketed ray is wider than 2*threshold, so the count is batch-global."""
+    work = (f_low > 0) & (f_high < 0)
+    d_mid = (d_low + d_high) / 2.0
+    n_iter = 0
+    while work.any():
+        f_mid = sdf_fn(ray_o + ray_d * d_mid.unsqueeze(-1))
+        lo = f_mid > 0
+        hi = f_mid <= 0
+        if lo.sum() > 0:
+            d_low[lo] = d_mid[lo]
+            f_low[lo] = f_mid[lo]
+        if hi.sum() > 0:
+            d_high[hi] = d_mid[hi]
+            f_high[hi] = f_mid[hi]
+        d_mid = (d_low + d_high) / 2.0
+        work &= (d_high - d_low) > 2 * prm.sdf_threshold
+        n_iter += 1
+    p_mid = ray_o + ray_d * d_mid.unsqueeze(-1)
+    f_mid = sdf_fn(p_mid)
+    return p_mid, d_mid, f_mid, n_iter
+
+
+def ray_sampler(sdf_fn, ray_o, ray_d, min_dis, max_dis, prm: TracerParams):
+    """raytracer.py:142-197."""
+    n = prm.n_steps
+    lin = torch.linspace(0, 1, steps=n).float().view(1, n)
+    z = min_dis.unsqueeze(-1) + lin * (max_dis.unsqueeze(-1) - min_dis.unsqueeze(-1))
+    pts = ray_o.unsqueeze(-2) + ray_d.unsqueeze(-2) * z.unsqueeze(-1)
+    vals = [sdf_fn(c) for c in torch.split(pts.reshape(-1, 3), prm.max_num_pts, dim=0)]
+    val = torch.cat(vals, dim=0).reshape(-1, n)
+
+    out_p = torch.zeros_like(ray_d)
+    out_s = torch.zeros_like(min_dis)
+    out_t = torch.zeros_like(min_dis)
+    weights = torch.arange(n, 0, -1).float().reshape(1, n)
+    mn, idx = torch.min(torch.sign(val) * weights, dim=-1)
+    root = (mn < 0.0) & (idx >= 1)
+    n_iter = 0
+    if root.sum() > 0:
+        i1 = idx[root].unsqueeze(-1)
+        z_lo = torch.gather(z[root], -1, i1 - 1).squeeze(-1)
+        f_lo = torch.gather(val[root], -1, i1 - 1).squeeze(-1)
+        z_hi = torch.gather(z[root], -1, i1).squeeze(-1)
+        f_hi = torch.gather(val[root], -1, i1).squeeze(-1)
+        p, t, s, n_iter = rootfind(sdf_fn, f_lo, f_hi, z_lo, z_hi, ray_o[root], ray_d[root], prm)
+        out_p[root] = p
+        out_s[root] = s
+        out_t[root] = t
+    return root, out_p, out_s, out_t, n_iter
+
+
+def raytracer_forward(sdf_fn, ray_o, ray_d, min_dis, max_dis, work_mask,
+                      prm: TracerParams = TracerParams(), stats: Optional[dict] = None) -> Dict[str, Tensor]:
+    """raytracer.py:45-103 (non-verbose).  `stats` (optional) receives n_sampler / n_bisect_iters."""
+    conv, unfinished, p, s, t = sphere_tracing(sdf_fn, ray_o, ray_d, min_dis, max_dis, work_mask, prm)
+    smask = unfinished
+    n_iter = 0
+    if smask.sum() > 0:
+        pos = (s[smask] > 0.0).float()
+        s_min = pos * t[smask] + (1.0 - pos) * min_dis[smask]
+        s_max = pos * max_dis[smask] + (1.0 - pos) * t[smask]
+        sc, sp, ss, st, n_iter = ray_sampler(sdf_fn, ray_o[smask], ray_d[smask], s_min, s_max, prm)
+        conv[smask] = sc
+        p[smask] = sp
+        s[smask] = ss
+        t[smask] = st
+    if stats is not None:
+        stats["n_sampler"] = stats.get("n_sampler", 0) + int(smask.sum())
+        stats.setdefault("bisect_iters", []).append(n_iter)
+    return {"convergent_mask": conv, "points": p, "sdf": s, "distance": t}
+
+
+# ----------------------------------------------------------------------------
+# stage-2 assembly -- models/raytracer.py:367-409, 542-552, 593-662, 778-814
+#                     render_surface.py:117-156 (render_fn)
+# ----------------------------------------------------------------------------
+@dataclass
+class Scene:
+    """Everything a render needs, as plain CPU tensors."""
+    sdf_sd: Dict[str, Tensor]
+    sdf_spec: SDFSpec
+    nets: Dict[str, Tuple[Dict[str, Tensor], RenderSpec]]
+    light: float
+    mts_trans: Tensor
+    mts_diff_trans: Tensor
+    counter: EvalCounter = field(default_factory=EvalCounter)
+
+    def sdf_fn(self, x: Tensor) -> Tensor:
+        self.counter.evals += int(x.shape[0])
+        return sdf_forward(self.sdf_sd, self.sdf_spec, x)[..., 0]
+
+
+@torch.no_grad()
+def raytrace_pixels(scene: Scene, uv: Tensor, cam: CameraSpec, mask: Optional[Tensor] = None,
+                    max_num_rays: int = 200000, prm: TracerParams = TracerParams(),
+                    stats: Optional[dict] = None) -> Dict[str, Tensor]:
+    """raytracer.py:367-409."""
+    if mask is None:
+        mask = torch.ones_like(uv[..., 0]).bool()
+    sh = list(uv.shape[:-1])
+    ray_o, ray_d, ray_d_norm = cam.get_rays(uv)
+    merged: Dict[str, List[Tensor]] = {}
+    for o_c, d_c, n_c, m_c in zip(torch.split(ray_o.reshape(-1, 3), max_num_rays, dim=0),
+                                  torch.split(ray_d.reshape(-1, 3), max_num_rays, dim=0),
+                                  torch.split(ray_d_norm.reshape(-1), max_num_rays, dim=0),
+                                  torch.split(mask.reshape(-1), max_num_rays, dim=0)):
+        hit, near, far = intersect_sphere(o_c, d_c, 1.0)
+        res = raytracer_forward(scene.sdf_fn, o_c, d_c, near, far, hit & m_c, prm, stats)
+        res["depth"] = res["distance"] / n_c
+        for k, v in res.items():
+            merged.setdefault(k, []).append(v)
+    out: Dict[str, Tensor] = {}
+    for k, parts in merged.items():
+        v = torch.cat(parts, dim=0).reshape(sh + [-1])
+        out[k] = v[..., 0] if v.shape[-1] == 1 else v
+    out.update({"uv": uv, "ray_o": ray_o, "ray_d": ray_d, "ray_d_norm": ray_d_norm})
+    return out
+
+
+@torch.no_grad()
+def raytrace_camera(scene: Scene, cam: CameraSpec, max_num_rays: int = 200000,
+                    prm: TracerParams = TracerParams(), stats: Optional[dict] = None) -> Dict[str, Tensor]:
+    """raytracer.py:542-552 (fill_holes=False, detect_edges=False)."""
+    res = raytrace_pixels(scene, cam.get_uv(), cam, max_num_rays=max_num_rays, prm=prm, stats=stats)
+    res["depth"] *= res["convergent_mask"].float()
+    return res
+
+
+def render_fn_ggx(scene: Scene, interior_mask: Tensor, ray_o: Tensor, ray_d: Tensor, points: Tensor,
+                  normals: Tensor, feats: Tensor) -> Dict[str, Tensor]:
+    """render_surface.py:117-156 with the GGX renderer."""
+    sh = list(interior_mask.shape)
+    rgb = torch.zeros(sh + [3], dtype=torch.float32)
+    out = {k: rgb.clone() for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo",
+                                    "specular_albedo", "normal")}
+    out["specular_roughness"] = rgb[..., 0].clone()
+    if interior_mask.any():
+        n = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+        prm = get_materials(scene.nets, points, n, feats)
+        res = ggx_colocated(torch.tensor(scene.light, dtype=torch.float32),
+                            (points - ray_o).norm(dim=-1, keepdim=True), n, -ray_d, prm,
+                            scene.mts_trans, scene.mts_diff_trans)
+        out["color"][interior_mask] = res["rgb"]
+        out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
+        out["specular_color"][interior_mask] = res["specular_rgb"]
+        out["diffuse_albedo"][interior_mask] = prm["diffuse_albedo"]
+        out["specular_albedo"][interior_mask] = prm["specular_albedo"]
+        out["specular_roughness"][interior_mask] = prm["specular_roughness"].squeeze(-1)
+        out["normal"][interior_mask] = n
+    return out
+
+
+def render_normal_and_color(scene: Scene, results: Dict[str, Tensor], max_num_pts: int = 320000) -> None:
+    """raytracer.py:593-662 (is_training=False); mutates `results`."""
+    sh = list(results["convergent_mask"].shape)
+    merged: Dict[str, List[Tensor]] = {}
+    for p_c, d_c, o_c, m_c in zip(torch.split(results["points"].reshape(-1, 3), max_num_pts, dim=0),
+                                  torch.split(results["ray_d"].reshape(-1, 3), max_num_pts, dim=0),
+                                  torch.split(results["ray_o"].reshape(-1, 3), max_num_pts, dim=0),
+                                  torch.split(results["convergent_mask"].reshape(-1), max_num_pts, dim=0)):
+        if m_c.any():
+            p_h, d_h, o_h = p_c[m_c], d_c[m_c], o_c[m_c]
+            _, feat, grad = sdf_get_all(scene.sdf_sd, scene.sdf_spec, p_h)
+        else:
+            p_h = d_h = o_h = grad = feat = torch.zeros(0, dtype=torch.float32)
+        with torch.no_grad():
+            r = render_fn_ggx(scene, m_c, o_h, d_h, p_h, grad, feat)
+        for k, v in r.items():
+            merged.setdefault(k, []).append(v)
+    for k, parts in merged.items():
+        v = torch.cat(parts, dim=0).reshape(sh + [-1])
+        results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+
+
+def render_camera(scene: Scene, cam: CameraSpec, prm: TracerParams = TracerParams(),
+                  stats: Optional[dict] = None) -> Dict[str, Tensor]:
+    """raytracer.py:778-814 with fill_holes=False, handle_edges=False, is_training=False."""
+    res = raytrace_camera(scene, cam, max_num_rays=50000, prm=prm, stats=stats)
+    render_normal_and_color(scene, res, max_num_pts=320000)
+    return res
+
+
+# ----------------------------------------------------------------------------
+# algorithmic work
+# ----------------------------------------------------------------------------
+FLOP_PER_SDF_EVAL = 2 * (39 * 256 + 2 * 256 * 256 + 256 * 217 + 4 * 256 * 256 + 256 * 1)  # 918 016
+FLOP_PER_HIT = 2 * (524544 + 459008 + 818176)  # 3 603 456
+
+
+def algorithmic_flop(n_evals: int, n_hits: int) -> int:
+    return FLOP_PER_SDF_EVAL * n_evals + FLOP_PER_HIT * n_hits

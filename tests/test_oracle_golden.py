@@ -1,0 +1,133 @@
+"""Pins oracle/iron_ref.py (and the build's own constructors) to golden vectors that
+tests/golden/make_golden.py recorded from the real reference.  CPU only.
+
+The oracle repeats the reference's torch op sequence, so on the torch build the fixtures were made
+with the results are bit-identical; the tolerances below only leave room for a different torch /
+MKL build on the GPU box (they are ~1 ulp-level, far below any parity tolerance used elsewhere).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iron_ref as R
+from iron_amd import scenes
+
+from _util import golden, golden_meta, oracle_scene, state_hash, t, tables
+
+TIGHT = dict(rtol=2e-6, atol=2e-7)
+
+
+@pytest.fixture(scope="module")
+def nets_s1():
+    return scenes.build_networks("S1")
+
+
+def test_constructors_reproduce_reference_state():
+    """The build's SDFNetwork / RenderingNetwork constructors consume the RNG like the reference's
+    (models/fields.py:47-76): seeded state dicts hash to the value recorded from the reference."""
+    meta = golden_meta()
+    for scene in ("S0", "S1"):
+        assert state_hash(scenes.build_networks(scene)) == meta["state_sha256_" + scene]
+
+
+def test_g1_positional_encoding():
+    g = golden("g1_pe.npz")
+    x = t(g["x"])
+    for L in (4, 6, 10):
+        out = R.positional_encoding(x, L).numpy()
+        assert out.shape[1] == R.pe_width(L)
+        np.testing.assert_allclose(out, g["pe%d" % L], **TIGHT)
+
+
+def test_g2_sdf_forward_and_get_all(nets_s1):
+    g = golden("g2_sdf.npz")
+    sc = oracle_scene(nets_s1)
+    x = t(g["x"])
+    full = R.sdf_forward(sc.sdf_sd, sc.sdf_spec, x).numpy()
+    np.testing.assert_allclose(full[:, 0], g["sdf"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(full[:256, 1:], g["feature256"], rtol=1e-5, atol=1e-6)
+    y, feat, grad = R.sdf_get_all(sc.sdf_sd, sc.sdf_spec, x)
+    np.testing.assert_allclose(y[:, 0].numpy(), g["getall_sdf"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(grad.numpy(), g["getall_grad"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(feat[:256].numpy(), g["getall_feature256"], rtol=1e-5, atol=1e-6)
+
+
+def test_g3_material_networks(nets_s1):
+    g = golden("g3_materials.npz")
+    sc = oracle_scene(nets_s1)
+    p, n, f = t(g["points"]), t(g["normals"]), t(g["features"])
+    for key, name, view in (("raw_diffuse", "diffuse_albedo_network", -n), ("raw_specular", "specular_albedo_network", None),
+                            ("raw_roughness", "specular_roughness_network", None)):
+        sd, spec = sc.nets[name]
+        out = R.rendering_forward(sd, spec, p, n, view, f).numpy()
+        np.testing.assert_allclose(out, g[key], rtol=1e-5, atol=1e-6)
+    m = R.get_materials(sc.nets, p, n, f)
+    for k in ("diffuse_albedo", "specular_albedo", "specular_roughness"):
+        np.testing.assert_allclose(m[k].numpy(), g[k], rtol=1e-5, atol=1e-6)
+
+
+def test_g4_ggx():
+    g = golden("g4_ggx.npz")
+    mt, md = tables()
+    prm = {"diffuse_albedo": t(g["diffuse_albedo"]), "specular_albedo": t(g["specular_albedo"]),
+           "specular_roughness": t(g["specular_roughness"])}
+    res = R.ggx_colocated(torch.tensor(float(g["light"])), t(g["distance"]), t(g["normal"]), t(g["viewdir"]), prm, mt, md)
+    for k in ("diffuse_rgb", "specular_rgb", "rgb"):
+        np.testing.assert_allclose(res[k].numpy(), g[k], rtol=1e-6, atol=1e-30)
+
+
+def test_g5_rays_and_sphere():
+    g = golden("g5_rays.npz")
+    cam = R.CameraSpec(512, 512, t(g["K"]), t(g["W2C"]))
+    o, d, dn = cam.get_rays(t(g["uv"]))
+    np.testing.assert_allclose(d.numpy(), g["ray_d"], **TIGHT)
+    np.testing.assert_allclose(dn.numpy(), g["ray_d_norm"], **TIGHT)
+    np.testing.assert_allclose(o.numpy(), g["ray_o"], **TIGHT)
+    m, near, far = R.intersect_sphere(o.reshape(-1, 3), d.reshape(-1, 3), 1.0)
+    assert np.array_equal(m.numpy(), g["mask"])
+    np.testing.assert_allclose(near.numpy(), g["near"], **TIGHT)
+    np.testing.assert_allclose(far.numpy(), g["far"], **TIGHT)
+    crop = cam.crop(64, 64, (224, 224))
+    np.testing.assert_allclose(crop.K.numpy(), g["crop_K"], rtol=0, atol=0)
+    np.testing.assert_allclose(crop.get_uv().numpy(), g["crop_uv"], rtol=0, atol=0)
+    _, dc, dnc = crop.get_rays(crop.get_uv())
+    np.testing.assert_allclose(dc.numpy(), g["crop_ray_d"], **TIGHT)
+    np.testing.assert_allclose(dnc.numpy(), g["crop_ray_d_norm"], **TIGHT)
+
+
+@pytest.mark.parametrize("scene,tag", [("S0", "c0"), ("S1", "c0"), ("S0", "v128"), ("S1", "v128")])
+def test_g6_g7_trace_and_render(scene, tag):
+    """RayTracer.forward chain + render_camera end to end, incl. the reference's eval count E."""
+    g = golden("g67_%s_%s.npz" % (scene, tag))
+    sc = oracle_scene(scenes.build_networks(scene), light=golden_meta()["light"])
+    cam = R.CameraSpec(int(g["W"]), int(g["H"]), t(g["K"]), t(g["W2C"]))
+    torch.set_num_threads(8)
+    tr = R.raytrace_camera(sc, cam, max_num_rays=50000)
+    assert sc.counter.evals == int(g["trace_evals"])
+    flips = int((tr["convergent_mask"].numpy() != g["convergent_mask"]).sum())
+    assert flips == 0
+    for k in ("distance", "sdf", "depth", "ray_d_norm"):
+        np.testing.assert_allclose(tr[k].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    for k in ("points", "ray_d"):
+        np.testing.assert_allclose(tr[k].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    R.render_normal_and_color(sc, tr)
+    for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "specular_roughness",
+              "normal"):
+        assert tr[k].shape == g[k].shape, k
+        np.testing.assert_allclose(tr[k].numpy(), g[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    assert int(tr["convergent_mask"].sum()) == int(g["n_conv"])
+
+
+def test_result_dict_contract():
+    """Key set / shapes / dtypes of render_camera."""
+    sc = oracle_scene(scenes.build_networks("S0"))
+    K, W2C = scenes.fixture_camera_matrices(16, 16)
+    res = R.render_camera(sc, R.CameraSpec(16, 16, K, W2C))
+    want = {"convergent_mask": (16, 16), "points": (16, 16, 3), "sdf": (16, 16), "distance": (16, 16), "depth": (16, 16),
+            "uv": (16, 16, 2), "ray_o": (16, 16, 3), "ray_d": (16, 16, 3), "ray_d_norm": (16, 16), "color": (16, 16, 3),
+            "diffuse_color": (16, 16, 3), "specular_color": (16, 16, 3), "diffuse_albedo": (16, 16, 3),
+            "specular_albedo": (16, 16, 3), "specular_roughness": (16, 16), "normal": (16, 16, 3)}
+    assert set(res.keys()) == set(want.keys())
+    for k, sh in want.items():
+        assert tuple(res[k].shape) == sh, k
+    assert res["convergent_mask"].dtype == torch.bool
