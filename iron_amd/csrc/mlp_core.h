@@ -134,8 +134,16 @@ struct WQueue {
     }
 };
 
+#ifndef IRON_SCHED_MASK
+#define IRON_SCHED_MASK 0x6  // VALU|SALU may cross a step boundary; MFMA and VMEM may not
+#endif
+
 // acc{0,1} += W[pair] * in  for a 256-wide input held as 8 register tiles; PAIR is compile-time so
-// that FIFO slots are static registers.  Refills steps g+D of the same layer (< 128).
+// that FIFO slots are static registers.  The stream is linear in memory across pairs AND across
+// consecutive hidden layers, so the FIFO simply keeps prefetching step g+D: at the end of a layer
+// it is already primed for the next one (the blob is padded, and buffer loads are range-checked).
+// sched_barrier pins each step's two loads in front of its eight MFMAs: without it hipcc sinks
+// every load to just before its first use and the L2 latency is exposed once per step.
 template <int PAIR>
 __device__ __forceinline__ void dense_hidden_pair(const WStream& ws, uint32_t base, WQueue& wq,
                                                   const f32x16 (&in)[kHidTiles], f32x16& acc0, f32x16& acc1) {
@@ -145,12 +153,11 @@ __device__ __forceinline__ void dense_hidden_pair(const WStream& ws, uint32_t ba
         const int g = PAIR * 32 + s;
         const int slot = g % D;
         const f32x4 x0 = wq.a0[slot], x1 = wq.a1[slot];
-        if (g + D < 128) {
-            wq.a0[slot] = ws.frag(base + (uint32_t)(g + D) * 2048u);
-            wq.a1[slot] = ws.frag(base + (uint32_t)(g + D) * 2048u + 1024u);
-        }
+        wq.a0[slot] = ws.frag(base + (uint32_t)(g + D) * 2048u);
+        wq.a1[slot] = ws.frag(base + (uint32_t)(g + D) * 2048u + 1024u);
         const int ti = s >> 2, q = s & 3;
         mfma_quad(x0, x1, in[ti][4 * q], in[ti][4 * q + 1], in[ti][4 * q + 2], in[ti][4 * q + 3], acc0, acc1);
+        __builtin_amdgcn_sched_barrier(IRON_SCHED_MASK);
     }
 }
 
@@ -188,10 +195,8 @@ constexpr int kSdfHeadQuads = head_slots(kSdfPeLevels) / 4;  // 20 slots -> 5 qu
 // one 256 -> 256 layer (+ optional head product), activation ACT applied, result in `out`
 template <class Act, int NQ>
 __device__ __forceinline__ void hidden_layer(const WStream& ws, uint32_t w_base, uint32_t b_base, bool with_head,
-                                             uint32_t head_base, const float* head, const f32x16 (&in)[kHidTiles],
-                                             f32x16 (&out)[kHidTiles], Act act) {
-    WQueue wq;
-    wq.prime(ws, w_base);
+                                             uint32_t head_base, const float* head, WQueue& wq,
+                                             const f32x16 (&in)[kHidTiles], f32x16 (&out)[kHidTiles], Act act) {
 #define IRON_PAIR(P)                                                                  \
     {                                                                                 \
         f32x16 a0 = load_half_tile(ws, b_base, 2 * P);                                \
@@ -234,12 +239,14 @@ __device__ __forceinline__ void sdf_hidden_stack(const SdfNetDev& n, const WStre
         h[2 * p] = softplus_tile<FAST>(a0);
         h[2 * p + 1] = softplus_tile<FAST>(a1);
     }
-    // layers 1 .. n_hidden-1: 256 -> 256 (+ PE at the skip layer)
+    // layers 1 .. n_hidden-1: 256 -> 256 (+ PE at the skip layer); one weight FIFO runs through all of them
+    WQueue wq;
+    wq.prime(ws, n.w_hid);
     for (int l = 1; l < n.n_hidden_layers; ++l) {
         const uint32_t w = n.w_hid + (uint32_t)(l - 1) * (kF4PerHidLayer * 16u);
         const uint32_t b = n.bias + (uint32_t)l * (kF4PerBiasLayer * 16u);
         f32x16 o[kHidTiles];
-        hidden_layer<SoftplusAct<FAST>, kSdfHeadQuads>(ws, w, b, l == n.skip_layer, n.w_pe_skip, pe, h, o,
+        hidden_layer<SoftplusAct<FAST>, kSdfHeadQuads>(ws, w, b, l == n.skip_layer, n.w_pe_skip, pe, wq, h, o,
                                                        SoftplusAct<FAST>());
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) h[t] = o[t];

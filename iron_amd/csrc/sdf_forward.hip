@@ -45,7 +45,9 @@ __global__ __launch_bounds__(64, 1) void k_sdf_full(SdfNetDev net, const float* 
         const float s = (row_dot(ws, net.w_last, h) + net.b_last) / net.scale;
         if (ok && lane < 32) out[idx * ld] = s;
         f32x16 o[kHidTiles];
-        hidden_layer<IdentityAct, 1>(ws, net.w_feat, net.b_feat, false, 0u, nullptr, h, o, IdentityAct());
+        WQueue wq;
+        wq.prime(ws, net.w_feat);
+        hidden_layer<IdentityAct, 1>(ws, net.w_feat, net.b_feat, false, 0u, nullptr, wq, h, o, IdentityAct());
         if (ok) {
 #pragma unroll
             for (int t = 0; t < kHidTiles; ++t)

@@ -1,1 +1,97 @@
-"""placeholder - filled in with get_materials below"""
+"""Material query + the stage-2 render_fn, with the reference's surface:
+    get_materials            <- models/rendering_func.py:5-16
+    make_render_fn(renderer) <- the driver's render_fn closure, render_surface.py:117-156
+
+`make_render_fn` returns a callable with the reference render_fn signature
+(interior_mask, color_network_dict, ray_o, ray_d, points, normals, features) -> dict.  When
+iron_amd.raytracer.render_normal_and_color sees it, it uses the attached fused path instead
+(one `iron_shade_ggx` launch: get_all + normalise + 3 material MLPs + GGX + scatter); called
+directly it runs the same steps through the per-operator HIP entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import torch
+
+from . import _lib
+
+
+def get_materials(network_dict, points, normals, features, is_metal=False):
+    """models/rendering_func.py:5-16."""
+    diffuse_albedo = network_dict["diffuse_albedo_network"](points, normals, -normals, features).abs()
+    specular_albedo = network_dict["specular_albedo_network"](points, normals, None, features).abs()
+    if not is_metal:
+        specular_albedo = torch.mean(specular_albedo, dim=-1, keepdim=True).expand_as(specular_albedo)
+    specular_roughness = network_dict["specular_roughness_network"](points, normals, None, features).abs() + 0.01
+    return {"diffuse_albedo": diffuse_albedo, "specular_albedo": specular_albedo,
+            "specular_roughness": specular_roughness}
+
+
+_OUT_KEYS = ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "specular_roughness",
+             "normal")
+
+
+class GGXRenderFn:
+    """render_surface.py:117-156 as a callable object."""
+
+    def __init__(self, renderer, is_metal: bool = False):
+        self.renderer = renderer
+        self.is_metal = is_metal
+
+    # -- generic path: same steps as the reference closure, each through its HIP operator -----------
+    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features):
+        dots_sh = list(interior_mask.shape)
+        dev = interior_mask.device
+        rgb = torch.zeros(dots_sh + [3], dtype=torch.float32, device=dev)
+        out = {k: rgb.clone() for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo",
+                                        "specular_albedo", "normal")}
+        out["specular_roughness"] = rgb[..., 0].clone()
+        if interior_mask.any():
+            normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+            params = get_materials(color_network_dict, points, normals, features, is_metal=self.is_metal)
+            light = color_network_dict["point_light_network"]()
+            res = self.renderer(float(light), (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d,
+                                params=params)
+            out["color"][interior_mask] = res["rgb"]
+            out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
+            out["specular_color"][interior_mask] = res["specular_rgb"]
+            out["diffuse_albedo"][interior_mask] = params["diffuse_albedo"]
+            out["specular_albedo"][interior_mask] = params["specular_albedo"]
+            out["specular_roughness"][interior_mask] = params["specular_roughness"].squeeze(-1)
+            out["normal"][interior_mask] = normals
+        return out
+
+    # -- fused path used by render_normal_and_color ---------------------------------------------------
+    def iron_fused_ggx(self, results: Dict[str, torch.Tensor], sdf_network, color_network_dict) -> Dict[str, torch.Tensor]:
+        pts = _lib.require_cuda_f32(results["points"], "points").reshape(-1, 3)
+        ray_o = _lib.require_cuda_f32(results["ray_o"], "ray_o").reshape(-1, 3)
+        ray_d = _lib.require_cuda_f32(results["ray_d"], "ray_d").reshape(-1, 3)
+        conv = results["convergent_mask"].reshape(-1).contiguous()
+        n = pts.shape[0]
+        dev = pts.device
+        lib = _lib.load()
+        nets = _lib.iron_shade_nets()
+        keep = [sdf_network.hip_net(), color_network_dict["diffuse_albedo_network"].hip_net(),
+                color_network_dict["specular_albedo_network"].hip_net(),
+                color_network_dict["specular_roughness_network"].hip_net()]
+        nets.sdf, nets.diffuse_albedo, nets.specular_albedo, nets.specular_roughness = [k.handle for k in keep]
+        bufs = {k: torch.empty((n,) if k == "specular_roughness" else (n, 3), dtype=torch.float32, device=dev)
+                for k in _OUT_KEYS}
+        so = _lib.iron_shade_out()
+        for k in _OUT_KEYS:
+            setattr(so, k, bufs[k].data_ptr())
+        t1, t2 = self.renderer._tables_on(dev)
+        ws_bytes = lib.iron_shade_workspace_bytes(n)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        light = float(color_network_dict["point_light_network"]())
+        with torch.cuda.device(dev):
+            _lib.check(lib.iron_shade_ggx(C.byref(nets), light, 1 if self.is_metal else 0, t1.data_ptr(), t2.data_ptr(),
+                                          ray_o.data_ptr(), ray_d.data_ptr(), pts.data_ptr(), conv.data_ptr(), n,
+                                          C.byref(so), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)))
+        return bufs
+
+
+def make_render_fn(renderer, is_metal: bool = False) -> GGXRenderFn:
+    return GGXRenderFn(renderer, is_metal=is_metal)
