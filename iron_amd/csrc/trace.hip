@@ -1,10 +1,445 @@
-// placeholder until the tracer kernels land (replaced in the next commit)
-#include "iron_common.h"
-extern "C" size_t iron_trace_workspace_bytes(int64_t, const iron_trace_params*) { return 0; }
-extern "C" int iron_trace(const iron_net_t*, const iron_trace_params*, const float*, const float*, const float*,
-                          const float*, const float*, const uint8_t*, int64_t, uint8_t*, float*, float*, float*,
-                          iron_trace_stats*, void*, size_t, void*) { return IRON_ERR_UNSUPPORTED; }
-extern "C" int iron_trace_phase(int32_t, const iron_net_t*, const iron_trace_params*, const float*, const float*,
-                                const float*, const float*, const float*, const uint8_t*, const int64_t*, int64_t,
-                                int32_t*, int64_t, uint8_t*, float*, float*, float*, iron_trace_stats*, void*, size_t,
-                                void*) { return IRON_ERR_UNSUPPORTED; }
+// Sphere tracer: RayTracer.forward = sphere_tracing + ray_sampler + rootfind
+// (models/raytracer.py:45-220) as four persistent kernels on one stream, no host sync.
+//
+//   k_sphere   one wave owns 32 ray slots.  Every pass evaluates the SDF MLP for all 32 slots, then
+//              each slot steps or retires; retired slots are refilled from a global ray queue
+//              (ballot -> rank among free slots -> one atomicAdd per wave), so MFMA tiles stay full
+//              although rays finish after 1..17 evaluations.  Rays still unfinished after the
+//              iteration cap are appended to the sampler list.
+//   k_sampler  one wave per listed ray: the 128 dense samples are evaluated 32 at a time in march
+//              order and the search stops at the first block that holds a negative sample (the
+//              reference evaluates all 128 and then takes the first sign change: same result).
+//   k_bisect_a 32 bracketed rays per wave, each bisected until ITS interval is <= 2*threshold;
+//              records the per-ray count and atomicMax-es it into the ray's chunk.
+//   k_bisect_b the reference loops while ANY ray of the call is unfinished and updates ALL rays, so
+//              every ray runs the chunk-wide maximum count: finish the remaining iterations, then
+//              the final mid-point evaluation.
+#include "mlp_core.h"
+#include "ggx_core.h"
+
+namespace iron {
+
+#ifndef IRON_FAST_SOFTPLUS
+#define IRON_FAST_SOFTPLUS 1
+#endif
+constexpr bool kFastActT = IRON_FAST_SOFTPLUS != 0;
+
+struct TraceCounters {  // zeroed at the start of every call
+    int q_head;         // sphere-trace ray queue
+    int n_sampler;      // rays appended for dense sampling
+    int sampler_head;
+    int n_root;         // rays with a sign-change bracket
+    int root_head_a;
+    int root_head_b;
+    int pad[2];
+    long long n_evals;
+    long long n_sphere_conv;
+    long long n_conv_sampler;
+    long long pad2;
+};
+
+struct TraceWs {
+    TraceCounters* cnt;
+    int* sampler_list;  // [n]
+    int* root_list;     // [n]
+    float* root_lo;     // [n] by list position
+    float* root_hi;
+    float* root_flo;
+    float* root_fhi;
+    int* root_k;        // iterations done in phase A
+    int* chunk_iters;   // [n_chunks]
+};
+
+struct TraceArgs {
+    const float* ray_o;
+    const float* ray_d;
+    const float* near;
+    const float* far;
+    const uint8_t* work;
+    const int64_t* ray_index;  // may be null
+    const float* lin;
+    uint8_t* conv;
+    float* points;
+    float* sdf;
+    float* dist;
+    int n;
+    int n_steps;
+    int iters;
+    float thr;
+    long long chunk;
+};
+
+__device__ __forceinline__ int lane_rank(unsigned mask, int j) { return __popc(mask & ((1u << j) - 1u)); }
+
+__global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, TraceWs w) {
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+
+    bool active = false, unf = false, work = false, exhausted = false;
+    int ray = 0, steps = 0;
+    float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, t = 0.f, far = 0.f;
+    long long evals = 0, nconv = 0;
+
+    for (;;) {
+        // ---- refill free slots from the queue
+        const unsigned act = (unsigned)__ballot(active);
+        const int nfree = 32 - __popc(act);
+        if (nfree > 0 && !exhausted) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&w.cnt->q_head, nfree);
+            base = __shfl(base, 0, 64);
+            int avail = a.n - base;
+            avail = avail < 0 ? 0 : (avail > nfree ? nfree : avail);
+            if (base + nfree >= a.n) exhausted = true;
+            const int rank = lane_rank(~act, j);
+            if (!active && rank < avail) {
+                ray = base + rank;
+                const float ox = a.ray_o[3 * (size_t)ray], oy = a.ray_o[3 * (size_t)ray + 1], oz = a.ray_o[3 * (size_t)ray + 2];
+                dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+                t = a.near[ray];
+                far = a.far[ray];
+                work = a.work[ray] != 0;
+                unf = work;
+                px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;  // raytracer.py:110
+                steps = 0;
+                active = true;
+            }
+        }
+        const unsigned act2 = (unsigned)__ballot(active);
+        if (act2 == 0u) break;
+        evals += __popc(act2);
+
+        const float s = sdf_eval<kFastActT>(net, ws, px, py, pz, lane);
+
+        bool retire = false, to_sampler = false;
+        if (active) {
+            unf = unf && (fabsf(s) > a.thr) && (t < far);  // raytracer.py:114-116
+            if (!unf || steps == a.iters) {
+                retire = true;
+                to_sampler = unf;
+            } else {  // raytracer.py:123-125 (separate mul / add, p accumulates)
+                t += s;
+                px += dx * s; py += dy * s; pz += dz * s;
+                ++steps;
+            }
+        }
+        const unsigned samp = (unsigned)__ballot(to_sampler);
+        int sbase = 0;
+        if (samp) {
+            if (lane == 0) sbase = atomicAdd(&w.cnt->n_sampler, __popc(samp));
+            sbase = __shfl(sbase, 0, 64);
+        }
+        if (retire) {
+            if (lane < 32) {
+                const bool conv = work && !unf && (fabsf(s) <= a.thr) && (t < far);  // raytracer.py:128-133
+                a.conv[ray] = conv ? 1 : 0;
+                a.points[3 * (size_t)ray] = px; a.points[3 * (size_t)ray + 1] = py; a.points[3 * (size_t)ray + 2] = pz;
+                a.sdf[ray] = s;
+                a.dist[ray] = t;
+                if (to_sampler) w.sampler_list[sbase + lane_rank(samp, j)] = ray;
+                if (conv) ++nconv;
+            }
+            active = false;
+            px = py = pz = 0.f;
+        }
+    }
+    // per-wave stats
+    long long c = nconv;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
+        atomicAdd((unsigned long long*)&w.cnt->n_sphere_conv, (unsigned long long)c);
+    }
+}
+
+__global__ __launch_bounds__(64, 1) void k_sampler(SdfNetDev net, TraceArgs a, TraceWs w) {
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+    const int n_list = w.cnt->n_sampler;
+    long long evals = 0;
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&w.cnt->sampler_head, 1);
+        i = __shfl(i, 0, 64);
+        if (i >= n_list) break;
+        const int ray = w.sampler_list[i];
+        const float ox = a.ray_o[3 * (size_t)ray], oy = a.ray_o[3 * (size_t)ray + 1], oz = a.ray_o[3 * (size_t)ray + 2];
+        const float dx = a.ray_d[3 * (size_t)ray], dy = a.ray_d[3 * (size_t)ray + 1], dz = a.ray_d[3 * (size_t)ray + 2];
+        const float t = a.dist[ray], s0 = a.sdf[ray];
+        // raytracer.py:59-65: sample [t, far] if sdf > 0 else [near, t]
+        const bool pos = s0 > 0.0f;
+        const float smin = pos ? t : a.near[ray];
+        const float smax = pos ? a.far[ray] : t;
+        const float width = smax - smin;
+
+        bool root = false, done = false;
+        float z_lo = 0.f, f_lo = 0.f, z_hi = 0.f, f_hi = 0.f;
+        float prev_z = 0.f, prev_f = 0.f;
+        for (int blk = 0; blk * 32 < a.n_steps && !done; ++blk) {
+            const int idx = blk * 32 + j;
+            const bool in_range = idx < a.n_steps;
+            const float z = smin + a.lin[in_range ? idx : a.n_steps - 1] * width;  // raytracer.py:147-149
+            const float qx = ox + dx * z, qy = oy + dy * z, qz = oz + dz * z;       // raytracer.py:150
+            const float f = sdf_eval<kFastActT>(net, ws, qx, qy, qz, lane);
+            const int n_in = a.n_steps - blk * 32;
+            evals += n_in < 32 ? n_in : 32;
+            const unsigned neg = (unsigned)__ballot(in_range && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
+            if (neg) {
+                const int first = __ffs(neg) - 1;
+                const int gidx = blk * 32 + first;
+                done = true;
+                if (gidx >= 1) {  // raytracer.py:167
+                    root = true;
+                    z_hi = __shfl(z, first, 64);
+                    f_hi = __shfl(f, first, 64);
+                    const float zl = __shfl(z, first > 0 ? first - 1 : 0, 64);
+                    const float fl = __shfl(f, first > 0 ? first - 1 : 0, 64);
+                    z_lo = first > 0 ? zl : prev_z;
+                    f_lo = first > 0 ? fl : prev_f;
+                }
+            }
+            prev_z = __shfl(z, 31, 64);
+            prev_f = __shfl(f, 31, 64);
+        }
+        if (lane == 0) {
+            if (root) {
+                const int pos_l = atomicAdd(&w.cnt->n_root, 1);
+                w.root_list[pos_l] = ray;
+                w.root_lo[pos_l] = z_lo; w.root_hi[pos_l] = z_hi;
+                w.root_flo[pos_l] = f_lo; w.root_fhi[pos_l] = f_hi;
+            } else {  // raytracer.py:158-160, 75-78: sampled rays without a root get zeros
+                a.conv[ray] = 0;
+                a.points[3 * (size_t)ray] = 0.f; a.points[3 * (size_t)ray + 1] = 0.f; a.points[3 * (size_t)ray + 2] = 0.f;
+                a.sdf[ray] = 0.f;
+                a.dist[ray] = 0.f;
+            }
+        }
+    }
+    if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
+}
+
+__device__ __forceinline__ long long ray_chunk(const TraceArgs& a, int ray) {
+    const long long gi = a.ray_index ? a.ray_index[ray] : (long long)ray;
+    return a.chunk > 0 ? gi / a.chunk : 0;
+}
+
+// rootfind, per-ray part (raytracer.py:199-217)
+__global__ __launch_bounds__(64, 1) void k_bisect_a(SdfNetDev net, TraceArgs a, TraceWs w) {
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+    const int n_root = w.cnt->n_root;
+    const float thr2 = 2.0f * a.thr;
+    long long evals = 0;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.cnt->root_head_a, 32);
+        base = __shfl(base, 0, 64);
+        if (base >= n_root) break;
+        const int li = base + j;
+        const bool valid = li < n_root;
+        const int ray = valid ? w.root_list[li] : 0;
+        float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f;
+        bool work = false;
+        if (valid) {
+            ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
+            dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+            lo = w.root_lo[li]; hi = w.root_hi[li];
+            work = (w.root_flo[li] > 0.0f) && (w.root_fhi[li] < 0.0f);
+        }
+        float mid = (lo + hi) / 2.0f;
+        int k = 0;
+        unsigned wm;
+        while ((wm = (unsigned)__ballot(work)) != 0u) {
+            evals += __popc(wm);
+            const float f = sdf_eval<kFastActT>(net, ws, ox + dx * mid, oy + dy * mid, oz + dz * mid, lane);
+            if (work) {
+                if (f > 0.0f) lo = mid; else hi = mid;
+                mid = (lo + hi) / 2.0f;
+                ++k;
+                work = ((hi - lo) > thr2) && (k < 64);  // k < 64: exit bound for non-finite intervals
+            }
+        }
+        if (valid && lane < 32) {
+            w.root_lo[li] = lo; w.root_hi[li] = hi;
+            w.root_k[li] = k;
+            if (k > 0) atomicMax(&w.chunk_iters[ray_chunk(a, ray)], k);
+        }
+    }
+    if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
+}
+
+// rootfind, chunk-global remainder + final evaluation (raytracer.py:204-219)
+__global__ __launch_bounds__(64, 1) void k_bisect_b(SdfNetDev net, TraceArgs a, TraceWs w) {
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+    const int n_root = w.cnt->n_root;
+    long long evals = 0;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.cnt->root_head_b, 32);
+        base = __shfl(base, 0, 64);
+        if (base >= n_root) break;
+        const int li = base + j;
+        const bool valid = li < n_root;
+        const int ray = valid ? w.root_list[li] : 0;
+        float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f;
+        int remaining = 0;
+        if (valid) {
+            ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
+            dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+            lo = w.root_lo[li]; hi = w.root_hi[li];
+            remaining = w.chunk_iters[ray_chunk(a, ray)] - w.root_k[li];
+        }
+        float mid = (lo + hi) / 2.0f;
+        unsigned wm;
+        while ((wm = (unsigned)__ballot(remaining > 0)) != 0u) {
+            evals += __popc(wm);
+            const float f = sdf_eval<kFastActT>(net, ws, ox + dx * mid, oy + dy * mid, oz + dz * mid, lane);
+            if (remaining > 0) {
+                if (f > 0.0f) lo = mid; else hi = mid;
+                mid = (lo + hi) / 2.0f;
+                --remaining;
+            }
+        }
+        const float qx = ox + dx * mid, qy = oy + dy * mid, qz = oz + dz * mid;
+        const float f = sdf_eval<kFastActT>(net, ws, qx, qy, qz, lane);
+        const unsigned vm = (unsigned)__ballot(valid);
+        evals += __popc(vm);
+        if (valid && lane < 32) {  // raytracer.py:75-78: the sampler's mask overwrites convergent
+            a.conv[ray] = 1;
+            a.points[3 * (size_t)ray] = qx; a.points[3 * (size_t)ray + 1] = qy; a.points[3 * (size_t)ray + 2] = qz;
+            a.sdf[ray] = f;
+            a.dist[ray] = mid;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
+    }
+}
+
+__global__ void k_trace_stats(TraceWs w, iron_trace_stats* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out->n_evals = w.cnt->n_evals;
+        out->n_sphere_conv = w.cnt->n_sphere_conv;
+        out->n_sampler = w.cnt->n_sampler;
+        out->n_bisect = w.cnt->n_root;
+        out->n_conv = w.cnt->n_sphere_conv + w.cnt->n_root;
+        out->reserved[0] = out->reserved[1] = out->reserved[2] = 0;
+    }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t cnt, sampler_list, root_list, lo, hi, flo, fhi, k, chunk_iters, total;
+    int64_t n_chunks;
+};
+
+static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
+    WsLayout L;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    L.n_chunks = (p && p->chunk > 0) ? (n + p->chunk - 1) / p->chunk : 1;
+    if (L.n_chunks < 1) L.n_chunks = 1;
+    size_t o = 0;
+    L.cnt = o; o += align256(sizeof(TraceCounters));
+    L.chunk_iters = o; o += align256(sizeof(int) * (size_t)L.n_chunks);
+    L.sampler_list = o; o += align256(sizeof(int) * nn);
+    L.root_list = o; o += align256(sizeof(int) * nn);
+    L.lo = o; o += align256(sizeof(float) * nn);
+    L.hi = o; o += align256(sizeof(float) * nn);
+    L.flo = o; o += align256(sizeof(float) * nn);
+    L.fhi = o; o += align256(sizeof(float) * nn);
+    L.k = o; o += align256(sizeof(int) * nn);
+    L.total = o;
+    return L;
+}
+
+static int resident_waves() {
+    // single-wave workgroups, one wave per SIMD (the kernels need > 256 registers per lane)
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
+    cached = prop.multiProcessorCount * 4;
+    return cached;
+}
+
+}  // namespace iron
+
+using namespace iron;
+
+extern "C" size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params* p) {
+    if (n < 0) return 0;
+    return ws_layout(n, p).total;
+}
+
+extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps,
+                                const float* ray_o, const float* ray_d, const float* near, const float* far,
+                                const uint8_t* work, const int64_t* ray_index, int64_t n, int32_t* chunk_iters,
+                                int64_t n_chunks, uint8_t* conv, float* points, float* sdf_out, float* dist,
+                                iron_trace_stats* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sdf || sdf->desc.kind != IRON_NET_SDF || !p || n < 0 || (phase != 0 && phase != 1)) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (p->n_steps < 2 || p->n_steps > 4096 || p->sphere_tracing_iters < 0 || !(p->sdf_threshold > 0.0f)) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!lin_steps || !ray_o || !ray_d || !near || !far || !work || !conv || !points || !sdf_out || !dist || !workspace)
+        return IRON_ERR_BAD_ARG;
+    const WsLayout L = ws_layout(n, p);
+    if (workspace_bytes < L.total) return IRON_ERR_WORKSPACE;
+    if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
+    if (chunk_iters && n_chunks < 1) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    TraceWs w;
+    w.cnt = (TraceCounters*)(base + L.cnt);
+    w.sampler_list = (int*)(base + L.sampler_list);
+    w.root_list = (int*)(base + L.root_list);
+    w.root_lo = (float*)(base + L.lo);
+    w.root_hi = (float*)(base + L.hi);
+    w.root_flo = (float*)(base + L.flo);
+    w.root_fhi = (float*)(base + L.fhi);
+    w.root_k = (int*)(base + L.k);
+    w.chunk_iters = chunk_iters ? chunk_iters : (int*)(base + L.chunk_iters);
+    TraceArgs a;
+    a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.work = work; a.ray_index = ray_index;
+    a.lin = lin_steps; a.conv = conv; a.points = points; a.sdf = sdf_out; a.dist = dist;
+    a.n = (int)n; a.n_steps = p->n_steps; a.iters = p->sphere_tracing_iters; a.thr = p->sdf_threshold;
+    a.chunk = p->chunk > 0 ? p->chunk : 0;
+    const int waves = resident_waves();
+    if (phase == 0) {
+        IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, align256(sizeof(TraceCounters)), st));
+        if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));
+        else IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int) * (size_t)L.n_chunks), st));
+        const int64_t tiles = (n + 31) / 32;
+        hipLaunchKernelGGL(k_sphere, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        hipLaunchKernelGGL(k_sampler, dim3((unsigned)(n < waves ? n : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        hipLaunchKernelGGL(k_bisect_a, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+    } else {
+        const int64_t tiles = (n + 31) / 32;
+        hipLaunchKernelGGL(k_bisect_b, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        if (stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w, stats);
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_trace(const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps, const float* ray_o,
+                          const float* ray_d, const float* near, const float* far, const uint8_t* work, int64_t n,
+                          uint8_t* conv, float* points, float* sdf_out, float* dist, iron_trace_stats* stats,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = iron_trace_phase(0, sdf, p, lin_steps, ray_o, ray_d, near, far, work, nullptr, n, nullptr, 0, conv, points,
+                              sdf_out, dist, stats, workspace, workspace_bytes, stream);
+    if (rc != IRON_OK) return rc;
+    return iron_trace_phase(1, sdf, p, lin_steps, ray_o, ray_d, near, far, work, nullptr, n, nullptr, 0, conv, points,
+                            sdf_out, dist, stats, workspace, workspace_bytes, stream);
+}
