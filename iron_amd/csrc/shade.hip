@@ -1,9 +1,518 @@
-// placeholder until the shading kernels land (replaced in the next commit)
-#include "iron_common.h"
-extern "C" int iron_sdf_get_all(const iron_net_t*, const float*, int64_t, float*, float*, float*, void*) { return IRON_ERR_UNSUPPORTED; }
-extern "C" int iron_render_forward(const iron_net_t*, const float*, const float*, const float*, const float*, int64_t,
-                                   float*, void*) { return IRON_ERR_UNSUPPORTED; }
-extern "C" size_t iron_shade_workspace_bytes(int64_t) { return 0; }
-extern "C" int iron_shade_ggx(const iron_shade_nets*, float, int32_t, const float*, const float*, const float*,
-                              const float*, const float*, const uint8_t*, int64_t, const iron_shade_out*, void*,
-                              size_t, void*) { return IRON_ERR_UNSUPPORTED; }
+// Shading: render_normal_and_color (models/raytracer.py:593-662) with the driver's GGX render_fn
+// (render_surface.py:117-156), plus the standalone SDFNetwork.get_all and RenderingNetwork.forward.
+//
+//   k_compact     convergent rays -> hit list (ballot + one atomic per wave)
+//   k_sdf_grad    get_all (models/fields.py:120-137): a 4-wave workgroup owns 32 hit points.  Wave 0
+//                 runs the value pass; waves 1..3 run the FORWARD-MODE tangent of the same network
+//                 for d/dx, d/dy, d/dz (replacing autograd.grad): identical MFMA stream without bias,
+//                 with the layer's softplus derivative sigma(100 z) handed over by wave 0 through LDS
+//                 (double-buffered, one barrier per layer).  Features leave in the register-tile
+//                 layout so the material kernels reload them as B operands without a transpose.
+//   k_material    RenderingNetwork.forward (models/fields.py:203-239): one wave per 32 hits and net.
+//   k_ggx_shade   normalise, get_materials post-ops (models/rendering_func.py:5-16), GGX, scatter.
+#include "mlp_core.h"
+#include "ggx_core.h"
+
+namespace iron {
+
+#ifndef IRON_FAST_SOFTPLUS
+#define IRON_FAST_SOFTPLUS 1
+#endif
+constexpr bool kFastActS = IRON_FAST_SOFTPLUS != 0;
+
+// softplus(beta=100) and its derivative from one exponential.  torch backward (softplus_backward):
+// grad * e/(e+1) with e = exp(100 z) below the threshold, grad above it.
+template <bool FAST>
+__device__ __forceinline__ void softplus100_both(float z, float& h, float& s) {
+    const float t = z * 100.0f;
+    float e, l;
+    if constexpr (FAST) {
+        e = __builtin_amdgcn_exp2f(t * 1.44269504088896340736f);
+        l = __builtin_amdgcn_logf(1.0f + e) * (0.69314718055994530942f * 0.01f);
+    } else {
+        e = expf(t);
+        l = log1pf(e) / 100.0f;
+    }
+    const float sg = e / (e + 1.0f);
+    const bool lin = t > 20.0f;
+    h = lin ? z : l;
+    s = lin ? 1.0f : sg;
+}
+
+// d(head slots)/d(component c) for one vec3 source with LEVELS (the tangent of head_fill)
+template <int LEVELS>
+__device__ __forceinline__ void head_fill_tangent(float vx, float vy, float vz, int c, int half, float* slots) {
+    slots[0] = (half ? (c == 1) : (c == 0)) ? 1.0f : 0.0f;
+    slots[1] = (!half && c == 2) ? 1.0f : 0.0f;
+    const float v = c == 0 ? vx : (c == 1 ? vy : vz);
+#pragma unroll
+    for (int k = 0; k < LEVELS; ++k) {
+        const float f = (float)(1 << k);
+        float s, co;
+        sincosf(v * f, &s, &co);
+        const float d = half ? -(f * s) : (f * co);  // d sin = f cos, d cos = -f sin
+        slots[2 + 3 * k + 0] = c == 0 ? d : 0.0f;
+        slots[2 + 3 * k + 1] = c == 1 ? d : 0.0f;
+        slots[2 + 3 * k + 2] = c == 2 ? d : 0.0f;
+    }
+}
+
+__device__ __forceinline__ f32x16 zero_tile() {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+    return v;
+}
+
+struct GradArgs {
+    const float* x;        // [*,3] point source
+    const int* list;       // hit list (indices into x) or null = identity
+    const int* count_ptr;  // device count or null
+    int count;             // used when count_ptr == null
+    float* feat_packed;    // [tiles][8][16][64] or null
+    float* sdf_out;        // [count] (list order) or null
+    float* grad_out;       // [count,3] (list order) or null
+    float* feat_rows;      // [count,256] row-major or null
+};
+
+constexpr int kSBufFloats = kHidTiles * 16 * 64;  // one layer's sigma'(z) for 32 points: 32 KiB
+
+__global__ __launch_bounds__(256, 1) void k_sdf_grad(SdfNetDev net, GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x kSBufFloats
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_value = wave == 0;
+    const int axis = wave - 1;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int src = ok ? (a.list ? a.list[li] : li) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (ok) { px = a.x[3 * (size_t)src]; py = a.x[3 * (size_t)src + 1]; pz = a.x[3 * (size_t)src + 2]; }
+        const float sx = px * net.scale, sy = py * net.scale, sz = pz * net.scale;
+
+        float head[4 * kSdfHeadQuads];
+        if (is_value) head_fill<kSdfPeLevels>(sx, sy, sz, half, head);
+        else head_fill_tangent<kSdfPeLevels>(sx, sy, sz, axis, half, head);
+
+        f32x16 h[kHidTiles];
+        WQueue wq;
+        wq.prime(ws, net.w_hid);
+        for (int l = 0; l < net.n_hidden_layers; ++l) {
+            float* sbuf = lds + (l & 1) * kSBufFloats;
+            const uint32_t wb = net.w_hid + (uint32_t)(l > 0 ? l - 1 : 0) * (kF4PerHidLayer * 16u);
+            const uint32_t bb = net.bias + (uint32_t)l * (kF4PerBiasLayer * 16u);
+            const bool with_head = (l == 0) || (l == net.skip_layer);
+            const uint32_t hb = (l == 0) ? net.w_pe0 : net.w_pe_skip;
+            f32x16 o[kHidTiles];
+#define IRON_GPAIR(P)                                                                               \
+    {                                                                                               \
+        f32x16 a0 = is_value ? load_half_tile(ws, bb, 2 * P) : zero_tile();                         \
+        f32x16 a1 = is_value ? load_half_tile(ws, bb, 2 * P + 1) : zero_tile();                     \
+        if (with_head) dense_head_pair<kSdfHeadQuads>(ws, hb, P, head, a0, a1);                     \
+        if (l > 0) dense_hidden_pair<P>(ws, wb, wq, h, a0, a1);                                     \
+        if (is_value) {                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
+                float hv, sv;                                                                       \
+                softplus100_both<kFastActS>(a0[r], hv, sv);                                         \
+                a0[r] = hv;                                                                         \
+                sbuf[((2 * P) * 16 + r) * 64 + lane] = sv;                                          \
+                softplus100_both<kFastActS>(a1[r], hv, sv);                                         \
+                a1[r] = hv;                                                                         \
+                sbuf[((2 * P + 1) * 16 + r) * 64 + lane] = sv;                                      \
+            }                                                                                       \
+        }                                                                                           \
+        o[2 * P] = a0;                                                                              \
+        o[2 * P + 1] = a1;                                                                          \
+    }
+            IRON_GPAIR(0) IRON_GPAIR(1) IRON_GPAIR(2) IRON_GPAIR(3)
+#undef IRON_GPAIR
+            __syncthreads();
+            if (!is_value) {
+#pragma unroll
+                for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= sbuf[(t * 16 + r) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) h[t] = o[t];
+        }
+
+        if (is_value) {
+            const float s = (row_dot(ws, net.w_last, h) + net.b_last) / net.scale;
+            if (ok && lane < 32 && a.sdf_out) a.sdf_out[li] = s;
+            if ((a.feat_packed || a.feat_rows) && net.w_feat) {
+                f32x16 o[kHidTiles];
+                WQueue wf;
+                wf.prime(ws, net.w_feat);
+                hidden_layer<IdentityAct, 1>(ws, net.w_feat, net.b_feat, false, 0u, nullptr, wf, h, o, IdentityAct());
+                if (a.feat_packed) {
+                    float* dst = a.feat_packed + (size_t)tile * kSBufFloats;
+#pragma unroll
+                    for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64 + lane] = o[t][r];
+                }
+                if (a.feat_rows && ok) {
+#pragma unroll
+                    for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            a.feat_rows[(size_t)li * kHidden + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = o[t][r];
+                }
+            }
+        } else {
+            const float g = row_dot(ws, net.w_last, h);  // d out0 / d x_c  (scale cancels: (1/s) * d/d(s x) * s)
+            if (ok && lane < 32 && a.grad_out) a.grad_out[3 * (size_t)li + axis] = g;
+        }
+        __syncthreads();  // the next tile's layer 0 reuses sbuf[0]
+    }
+}
+
+// ---- material networks ------------------------------------------------------------------------------
+struct MatArgs {
+    const float* points;    // [*,3]
+    const float* normals;   // [*,3]   (un-normalised gradient when normalise != 0)
+    const float* view;      // [*,3] or null (view = -normal when neg_normal_view != 0)
+    const float* feat_rows; // [*,256] row-major or null
+    const float* feat_packed;  // [tiles][8][16][64] or null
+    const int* list;        // index into points (hit list) or null
+    const int* count_ptr;
+    int count;
+    int normalise;          // n = g / (|g| + 1e-10)   (render_surface.py:127)
+    int neg_normal_view;    // view_dirs = -normals    (rendering_func.py:7)
+    int list_order_aux;     // normals/view/feat_rows are indexed by list position (1) or by point index (0)
+    float* out;             // [count, d_out] in list order
+};
+
+// LP: PE levels on points, LV: PE levels on view dirs (HAS_VIEW), HAS_NRM: normals present
+template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
+struct HeadCfg {
+    static constexpr int kSlots = head_slots(LP) + (HAS_VIEW ? head_slots(LV) : 0) + (HAS_NRM ? 2 : 0);
+    static constexpr int kQuads = kSlots <= 20 ? 5 : 6;
+    static_assert(kSlots <= 24, "head too wide");
+};
+
+template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
+__global__ __launch_bounds__(64, 1) void k_material(RenderNetDev net, MatArgs a) {
+    using Cfg = HeadCfg<LP, LV, HAS_VIEW, HAS_NRM>;
+    constexpr int NQ = Cfg::kQuads;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    WStream ws;
+    ws.init(net.blob, net.blob_bytes, lane);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int pi = ok ? (a.list ? a.list[li] : li) : 0;
+        const int ai = ok ? (a.list_order_aux ? li : pi) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 1.f, vx = 0.f, vy = 0.f, vz = 0.f;
+        if (ok) {
+            px = a.points[3 * (size_t)pi]; py = a.points[3 * (size_t)pi + 1]; pz = a.points[3 * (size_t)pi + 2];
+            if (a.normals) { nx = a.normals[3 * (size_t)ai]; ny = a.normals[3 * (size_t)ai + 1]; nz = a.normals[3 * (size_t)ai + 2]; }
+            if (a.normalise) {
+                const float nn = sqrtf((nx * nx + ny * ny) + nz * nz) + 1e-10f;
+                nx = nx / nn; ny = ny / nn; nz = nz / nn;
+            }
+            if (a.neg_normal_view) { vx = -nx; vy = -ny; vz = -nz; }
+            else if (a.view) { vx = a.view[3 * (size_t)ai]; vy = a.view[3 * (size_t)ai + 1]; vz = a.view[3 * (size_t)ai + 2]; }
+        }
+        float head[4 * NQ];
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; ++i) head[i] = 0.0f;
+        int base = 0;
+        head_fill<LP>(px, py, pz, half, head + base);
+        base += head_slots(LP);
+        if constexpr (HAS_VIEW) { head_fill<LV>(vx, vy, vz, half, head + base); base += head_slots(LV); }
+        if constexpr (HAS_NRM) { head_fill<0>(nx, ny, nz, half, head + base); base += 2; }
+
+        // features -> register tiles (B-operand layout)
+        f32x16 h[kHidTiles];
+        if (a.feat_packed) {
+            const float* src = a.feat_packed + (size_t)tile * kSBufFloats;
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[t][r] = src[(t * 16 + r) * 64 + lane];
+        } else {
+            const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // features 32t + 8q + 4*half + 0..3 are contiguous
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) v = row[(32 * t + 8 * q + 4 * half) >> 2];
+                    h[t][4 * q] = v.x; h[t][4 * q + 1] = v.y; h[t][4 * q + 2] = v.z; h[t][4 * q + 3] = v.w;
+                }
+        }
+
+        // layer 0 (head + features) and the hidden layers share one linear weight stream
+        WQueue wq;
+        wq.prime(ws, net.w_feat0);
+        for (int l = 0; l < net.n_hidden_layers; ++l) {
+            const uint32_t wb = (l == 0) ? net.w_feat0 : net.w_hid + (uint32_t)(l - 1) * (kF4PerHidLayer * 16u);
+            const uint32_t bb = net.bias + (uint32_t)l * (kF4PerBiasLayer * 16u);
+            f32x16 o[kHidTiles];
+            hidden_layer<ReluAct, NQ>(ws, wb, bb, l == 0, net.w_head0, head, wq, h, o, ReluAct());
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) h[t] = o[t];
+        }
+        for (int c = 0; c < net.d_out; ++c) {
+            float v = row_dot(ws, net.w_last + (uint32_t)c * (kF4PerBiasLayer * 16u), h) + net.b_last[c];
+            v = net.output_scale * (v + net.output_bias);  // fields.py:235
+            if (net.squeeze_out) v = net.squeeze_out_scale * (1.0f / (1.0f + expf(-v)));  // fields.py:236-237
+            if (ok && lane < 32) a.out[(size_t)li * net.d_out + c] = v;
+        }
+    }
+}
+
+// ---- hit list + final pointwise stage ---------------------------------------------------------------
+__global__ void k_compact(const uint8_t* __restrict__ conv, int n, int* __restrict__ count, int* __restrict__ list) {
+    const int stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const int n_round = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool hit = i < n && conv[i] != 0;
+        const unsigned long long m = __ballot(hit);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+struct ShadeArgs {
+    const int* list;
+    const int* count_ptr;
+    const float* ray_o;
+    const float* ray_d;
+    const float* points;
+    const float* grad;   // [hits,3] list order
+    const float* raw_kd; // [hits,3]
+    const float* raw_ks; // [hits,3]
+    const float* raw_r;  // [hits,1]
+    const float* tab_trans;
+    const float* tab_diff;
+    float light;
+    int is_metal;
+    iron_shade_out out;
+};
+
+__global__ void k_ggx_shade(ShadeArgs a) {
+    const int count = *a.count_ptr;
+    const int stride = gridDim.x * blockDim.x;
+    for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < count; li += stride) {
+        const int ray = a.list[li];
+        const float g[3] = {a.grad[3 * (size_t)li], a.grad[3 * (size_t)li + 1], a.grad[3 * (size_t)li + 2]};
+        const float nn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]) + 1e-10f;  // render_surface.py:127
+        const float nrm[3] = {g[0] / nn, g[1] / nn, g[2] / nn};
+        const float p[3] = {a.points[3 * (size_t)ray], a.points[3 * (size_t)ray + 1], a.points[3 * (size_t)ray + 2]};
+        const float o[3] = {a.ray_o[3 * (size_t)ray], a.ray_o[3 * (size_t)ray + 1], a.ray_o[3 * (size_t)ray + 2]};
+        const float v[3] = {-a.ray_d[3 * (size_t)ray], -a.ray_d[3 * (size_t)ray + 1], -a.ray_d[3 * (size_t)ray + 2]};
+        const float e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+        const float dist = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+        // get_materials post-ops (rendering_func.py:7-11)
+        float kd[3], ks[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            kd[c] = fabsf(a.raw_kd[3 * (size_t)li + c]);
+            ks[c] = fabsf(a.raw_ks[3 * (size_t)li + c]);
+        }
+        if (!a.is_metal) {
+            const float m = ((ks[0] + ks[1]) + ks[2]) / 3.0f;
+            ks[0] = ks[1] = ks[2] = m;
+        }
+        const float rough = fabsf(a.raw_r[li]) + 0.01f;
+        GgxOut r;
+        ggx_colocated_point(a.light, dist, nrm, v, kd, ks, rough, a.tab_trans, a.tab_diff, r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (a.out.color) a.out.color[3 * (size_t)ray + c] = r.rgb[c];
+            if (a.out.diffuse_color) a.out.diffuse_color[3 * (size_t)ray + c] = r.diffuse[c];
+            if (a.out.specular_color) a.out.specular_color[3 * (size_t)ray + c] = r.specular[c];
+            if (a.out.diffuse_albedo) a.out.diffuse_albedo[3 * (size_t)ray + c] = kd[c];
+            if (a.out.specular_albedo) a.out.specular_albedo[3 * (size_t)ray + c] = ks[c];
+            if (a.out.normal) a.out.normal[3 * (size_t)ray + c] = nrm[c];
+        }
+        if (a.out.specular_roughness) a.out.specular_roughness[ray] = rough;
+    }
+}
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ShadeLayout {
+    size_t count, list, grad, kd, ks, rr, feat, total;
+};
+static ShadeLayout shade_layout(int64_t n) {
+    ShadeLayout L;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const size_t tiles = (nn + kTile - 1) / kTile;
+    size_t o = 0;
+    L.count = o; o += 256;
+    L.list = o; o += al256(sizeof(int) * nn);
+    L.grad = o; o += al256(sizeof(float) * 3 * nn);
+    L.kd = o; o += al256(sizeof(float) * 3 * nn);
+    L.ks = o; o += al256(sizeof(float) * 3 * nn);
+    L.rr = o; o += al256(sizeof(float) * nn);
+    L.feat = o; o += al256(sizeof(float) * kSBufFloats * tiles);
+    L.total = o;
+    return L;
+}
+
+static int cu_count() {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cached = prop.multiProcessorCount;
+    return cached;
+}
+
+static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st) {
+    const size_t lds_bytes = 2 * kSBufFloats * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_sdf_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int cus = cu_count();
+    const unsigned grid = (unsigned)(max_tiles < cus ? (max_tiles > 0 ? max_tiles : 1) : cus);
+    hipLaunchKernelGGL(k_sdf_grad, dim3(grid), dim3(256), lds_bytes, st, sdf->sdf, a);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+// dispatch on the head configuration the kernels are instantiated for
+static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_tiles, hipStream_t st) {
+    const RenderNetDev& r = net->rnd;
+    const int waves = cu_count() * 4;
+    const unsigned grid = (unsigned)(max_tiles < waves ? (max_tiles > 0 ? max_tiles : 1) : waves);
+    const iron_net_desc& d = net->desc;
+    const int lp = d.multires > 0 ? d.multires : 0;
+    const int lv = d.multires_view > 0 ? d.multires_view : 0;
+    if (d.mode == IRON_MODE_IDR && lp == 0 && lv == 4) {
+        hipLaunchKernelGGL((k_material<0, 4, true, true>), dim3(grid), dim3(64), 0, st, r, a);
+    } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
+        hipLaunchKernelGGL((k_material<6, 0, false, true>), dim3(grid), dim3(64), 0, st, r, a);
+    } else {
+        return IRON_ERR_UNSUPPORTED;
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+}  // namespace iron
+
+using namespace iron;
+
+extern "C" int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sdf_out, float* feature,
+                                float* grad, void* stream) {
+    if (!sdf || sdf->desc.kind != IRON_NET_SDF || n < 0 || (n > 0 && !x)) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (feature && !sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
+    if (n == 0) return IRON_OK;
+    GradArgs a;
+    a.x = x; a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n;
+    a.feat_packed = nullptr; a.sdf_out = sdf_out; a.grad_out = grad; a.feat_rows = feature;
+    return launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+}
+
+extern "C" int iron_render_forward(const iron_net_t* net, const float* points, const float* normals,
+                                   const float* view_dirs, const float* features, int64_t n, float* out, void* stream) {
+    if (!net || net->desc.kind != IRON_NET_RENDER || n < 0) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!points || !features || !out) return IRON_ERR_BAD_ARG;
+    if (((uintptr_t)features & 15) != 0) return IRON_ERR_BAD_ARG;
+    const int mode = net->desc.mode;
+    if ((mode == IRON_MODE_IDR || mode == IRON_MODE_NO_VIEW_DIR) && !normals) return IRON_ERR_BAD_ARG;
+    if ((mode == IRON_MODE_IDR || mode == IRON_MODE_NO_NORMAL) && !view_dirs) return IRON_ERR_BAD_ARG;
+    MatArgs a;
+    a.points = points; a.normals = normals; a.view = view_dirs; a.feat_rows = features; a.feat_packed = nullptr;
+    a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n; a.normalise = 0; a.neg_normal_view = 0;
+    a.list_order_aux = 1; a.out = out;
+    return launch_material(net, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+}
+
+extern "C" size_t iron_shade_workspace_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return shade_layout(n).total;
+}
+
+extern "C" int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t is_metal, const float* tab_trans,
+                              const float* tab_diff_trans, const float* ray_o, const float* ray_d, const float* points,
+                              const uint8_t* conv, int64_t n, const iron_shade_out* out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!nets || !nets->sdf || !nets->diffuse_albedo || !nets->specular_albedo || !nets->specular_roughness || !out)
+        return IRON_ERR_BAD_ARG;
+    if (nets->sdf->desc.kind != IRON_NET_SDF || !nets->sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
+    if (nets->diffuse_albedo->desc.d_out != 3 || nets->specular_albedo->desc.d_out != 3 ||
+        nets->specular_roughness->desc.d_out != 1)
+        return IRON_ERR_UNSUPPORTED;
+    if (n < 0 || n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!tab_trans || !tab_diff_trans || !ray_o || !ray_d || !points || !conv || !workspace) return IRON_ERR_BAD_ARG;
+    const ShadeLayout L = shade_layout(n);
+    if (workspace_bytes < L.total) return IRON_ERR_WORKSPACE;
+    if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    int* count = (int*)(base + L.count);
+    int* list = (int*)(base + L.list);
+    float* grad = (float*)(base + L.grad);
+    float* kd = (float*)(base + L.kd);
+    float* ks = (float*)(base + L.ks);
+    float* rr = (float*)(base + L.rr);
+    float* feat = (float*)(base + L.feat);
+
+    // non-hit pixels are zero in every output (render_surface.py:119-125)
+    IRON_HIP_TRY(hipMemsetAsync(count, 0, 256, st));
+    float* outs3[6] = {out->color, out->diffuse_color, out->specular_color, out->diffuse_albedo, out->specular_albedo, out->normal};
+    for (float* p : outs3)
+        if (p) IRON_HIP_TRY(hipMemsetAsync(p, 0, sizeof(float) * 3 * (size_t)n, st));
+    if (out->specular_roughness) IRON_HIP_TRY(hipMemsetAsync(out->specular_roughness, 0, sizeof(float) * (size_t)n, st));
+
+    {
+        const int64_t b = (n + 255) / 256;
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, st, conv, (int)n, count, list);
+    }
+    const int64_t max_tiles = (n + kTile - 1) / kTile;
+    GradArgs ga;
+    ga.x = points; ga.list = list; ga.count_ptr = count; ga.count = 0;
+    ga.feat_packed = feat; ga.sdf_out = nullptr; ga.grad_out = grad; ga.feat_rows = nullptr;
+    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st);
+    if (rc != IRON_OK) return rc;
+
+    MatArgs ma;
+    ma.points = points; ma.normals = grad; ma.view = nullptr; ma.feat_rows = nullptr; ma.feat_packed = feat;
+    ma.list = list; ma.count_ptr = count; ma.count = 0; ma.normalise = 1; ma.list_order_aux = 1;
+    ma.neg_normal_view = 1; ma.out = kd;
+    rc = launch_material(nets->diffuse_albedo, ma, max_tiles, st);
+    if (rc != IRON_OK) return rc;
+    ma.neg_normal_view = 0; ma.out = ks;
+    rc = launch_material(nets->specular_albedo, ma, max_tiles, st);
+    if (rc != IRON_OK) return rc;
+    ma.out = rr;
+    rc = launch_material(nets->specular_roughness, ma, max_tiles, st);
+    if (rc != IRON_OK) return rc;
+
+    ShadeArgs sa;
+    sa.list = list; sa.count_ptr = count; sa.ray_o = ray_o; sa.ray_d = ray_d; sa.points = points; sa.grad = grad;
+    sa.raw_kd = kd; sa.raw_ks = ks; sa.raw_r = rr; sa.tab_trans = tab_trans; sa.tab_diff = tab_diff_trans;
+    sa.light = light; sa.is_metal = is_metal; sa.out = *out;
+    {
+        const int64_t b = (n + 255) / 256;
+        hipLaunchKernelGGL(k_ggx_shade, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, st, sa);
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}

@@ -51,7 +51,7 @@ class GGXRenderFn:
         if interior_mask.any():
             normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
             params = get_materials(color_network_dict, points, normals, features, is_metal=self.is_metal)
-            light = color_network_dict["point_light_network"]()
+            light = color_network_dict["point_light_network"]().detach()
             res = self.renderer(float(light), (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d,
                                 params=params)
             out["color"][interior_mask] = res["rgb"]
@@ -85,7 +85,7 @@ class GGXRenderFn:
         t1, t2 = self.renderer._tables_on(dev)
         ws_bytes = lib.iron_shade_workspace_bytes(n)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        light = float(color_network_dict["point_light_network"]())
+        light = float(color_network_dict["point_light_network"]().detach())
         with torch.cuda.device(dev):
             _lib.check(lib.iron_shade_ggx(C.byref(nets), light, 1 if self.is_metal else 0, t1.data_ptr(), t2.data_ptr(),
                                           ray_o.data_ptr(), ray_d.data_ptr(), pts.data_ptr(), conv.data_ptr(), n,
