@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the stage-2 forward render (ray-gen -> sphere trace -> GGX shade ->
+pixels) on synthetic 800x800 views (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config C1): scene S0 (seed-0 geometric-init SDF, `ggx` material nets), fixture camera
+rescaled to 800x800, tracer defaults, fill_holes=False, handle_edges=False, fp32.
+  N = 1 : one step = render_camera() of one 800x800 view through the drop-in operator surface.
+  N > 1 : one step = N views (fixture pose orbited by k*45 deg), every view's rays sharded over the N ranks
+          by interleaved 32x32 tiles; one MAX all-reduce of the per-chunk bisection counts and one RCCL gather
+          of the finished pixel records to rank 0 per step.  Per-GPU work is fixed -> "scaling": "weak".
+One JSON line is printed by rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL = 918016          # one SDF evaluation (sdf only), 459 008 MAC
+FLOP_SDF_GRAD = 2 * (524544 + 459008)   # per hit: full forward (257 outs) + input gradient
+FLOP_MATERIALS = 2 * 818176             # per hit: the three material MLPs
+FLOP_PER_HIT = FLOP_SDF_GRAD + FLOP_MATERIALS
+PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--scene", default="S0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-res", type=int, default=160)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene: str, res: int):
+    """The oracle (torch-CPU port of the reference path) timed on this host on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import iron_ref as R
+    from iron_amd import scenes
+    from _util import oracle_scene
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sc = oracle_scene(scenes.build_networks(scene))
+    K, W2C = scenes.fixture_camera_matrices(res, res)
+    cam = R.CameraSpec(res, res, K, W2C)
+    R.render_camera(sc, R.CameraSpec(16, 16, *scenes.fixture_camera_matrices(16, 16)))  # warm the thread pool
+    sc.counter.evals = 0
+    t0 = time.perf_counter()
+    out = R.render_camera(sc, cam)
+    dt = time.perf_counter() - t0
+    return {"value": res * res / dt / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s %dx%d full view (fixture camera rescaled), trace+GGX shade, torch-CPU oracle, %.1f s" % (scene, res, res, dt),
+            "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean())}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from iron_amd import _lib, scenes
+    from iron_amd.raytracer import Camera, RayTracer, render_camera
+    from iron_amd.renderer_ggx import GGXColocatedRenderer
+    from iron_amd.rendering_func import make_render_fn
+    from iron_amd.sharding import ShardedRenderer
+    import iron_amd.raytracer as rt
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    nets = {k: v.to(dev) for k, v in scenes.build_networks(a.scene).items()}
+    sdf = nets["sdf_network"]
+    tracer = RayTracer()
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    n_views = world
+    cams = []
+    for v in range(n_views):
+        K, W2C = scenes.fixture_camera_matrices(a.res, a.res, yaw_deg=45.0 * v)
+        cams.append(Camera(a.res, a.res, K.to(dev), W2C.to(dev)))
+    sharded = ShardedRenderer(sdf, nets, tracer, fn, tile=32, chunk=50000) if world > 1 else None
+
+    def step(stats=False):
+        if world == 1:
+            rt.VERBOSE_MODE = stats
+            try:
+                return render_camera(cams[0], sdf, tracer, nets, fn, fill_holes=False, handle_edges=False, is_training=False)
+            finally:
+                rt.VERBOSE_MODE = False
+        return sharded.render(cams, collect_stats=stats)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # one extra (untimed) step for the work counters
+    res = step(stats=True)
+    torch.cuda.synchronize()
+    st = tracer.last_stats
+    cnt = torch.tensor([st["n_evals_ref"], st["n_evals"], st["n_conv"], st["n_evals_sphere"], st["n_sampler"], st["n_bisect"]],
+                       dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    E_ref, E_hip, H, E_sphere, n_sampler, n_bisect = [int(x) for x in cnt.tolist()]
+
+    if rank == 0:
+        rays = n_views * a.res * a.res
+        ms_per_step = dt / a.steps * 1e3
+        value = rays * a.steps / dt / 1e6
+        # oracle-counted work for this exact workload, if committed (tools/count_work.py)
+        E_oracle = H_oracle = None
+        wc_path = os.path.join(ROOT, "tests", "golden", "work_counts.json")
+        if world == 1 and os.path.exists(wc_path):
+            wc = json.load(open(wc_path)).get("%s_%d" % (a.scene, a.res))
+            if wc:
+                E_oracle, H_oracle = wc["E"], wc["H"]
+        E_alg = E_oracle if E_oracle is not None else E_ref
+        H_alg = H_oracle if H_oracle is not None else H
+        flop_frame = FLOP_PER_EVAL * E_alg + FLOP_PER_HIT * H_alg
+        # per-kernel device time (rank 0's launches, hipEvents on the launch stream inside the timed region)
+        alg = {"sphere": FLOP_PER_EVAL * E_sphere / world, "sampler": FLOP_PER_EVAL * n_sampler * tracer.n_steps / world,
+               "bisect_a": None, "bisect_b": None, "sdf_grad": FLOP_SDF_GRAD * H / world, "material": FLOP_MATERIALS * H / world / 3.0,
+               "ggx": None, "sdf_forward": None}
+        kernels = {}
+        for k, (ms, n) in prof.items():
+            if n:
+                kernels[k] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_total"]) if kernels else None
+        roof = None
+        if dom and alg.get(dom):
+            avg_s = kernels[dom]["ms_avg"] / 1e3
+            ach = alg[dom] / avg_s
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get(dom, {}).get("bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
+                    "algorithmic_flop_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["ms_avg"],
+                    "note": "algorithmic FLOP = 918016 x the evaluations the REFERENCE makes for this kernel's rays "
+                            "(the sampler stops at the first negative block, so it executes fewer)"}
+        out = {
+            "metric": "Mrays/s sphere-trace+GGX shade, drv/dragon 800x800 (synthetic S0)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
+                                   "sphere-trace + GGX shade, fp32" % (a.scene, a.res, a.res),
+                       "views_per_step": n_views, "rays_per_step": rays,
+                       "sharding": "none (render_camera)" if world == 1 else "interleaved 32x32 tiles over %d ranks, RCCL gather" % world,
+                       "tracer": {"sdf_threshold": 5e-5, "sphere_tracing_iters": 16, "n_steps": 128, "chunk": 50000}},
+            "roofline": roof,
+            "frame": {"E_reference_evals": E_alg, "E_source": "oracle (tests/golden/work_counts.json)" if E_oracle is not None else "device counters",
+                      "E_device_ref_equivalent": E_ref, "E_executed": E_hip, "H_hits": H_alg, "H_device": H,
+                      "algorithmic_flop_per_step": flop_frame, "achieved_tflops": flop_frame * a.steps / dt / 1e12,
+                      "frac_of_fp32_mfma_peak": flop_frame * a.steps / dt / PEAK_FP32_MFMA,
+                      "executed_tflops": (FLOP_PER_EVAL * E_hip + FLOP_PER_HIT * H) * a.steps / dt / 1e12},
+            "kernels": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.scene, a.cpu_sample_res)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

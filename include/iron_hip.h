@@ -143,7 +143,11 @@ typedef struct iron_trace_stats { /* written to DEVICE memory, all int64 */
     int64_t n_sampler;     /* rays handed to the dense sampler                                  */
     int64_t n_bisect;      /* rays bisected                                                     */
     int64_t n_conv;        /* convergent rays at the end                                        */
-    int64_t reserved[3];
+    int64_t n_evals_ref;   /* evaluations the REFERENCE algorithm makes on the same rays: sphere-trace
+                              evals + 128 per sampled ray + (chunk count + 1) per bisected ray
+                              (SURVEY 8d's E; the HIP sampler stops early, so n_evals <= n_evals_ref) */
+    int64_t n_evals_sphere;/* evaluations made by the sphere-tracing kernel                     */
+    int64_t reserved;
 } iron_trace_stats;
 
 size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params* p);
@@ -198,6 +202,20 @@ int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t is_metal, c
                    const float* tab_diff_trans, const float* ray_o, const float* ray_d, const float* points,
                    const uint8_t* conv, int64_t n, const iron_shade_out* out, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (no reference counterpart): per-kernel device time from hipEvents recorded on the
+ * caller's stream around each compute kernel.  Off by default.  iron_profile_read blocks on the
+ * recorded events, adds their elapsed milliseconds / launch counts into the caller's arrays
+ * (IRON_PROF_KINDS entries each) and clears the pending list.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    IRON_PROF_SPHERE = 0, IRON_PROF_SAMPLER = 1, IRON_PROF_BISECT_A = 2, IRON_PROF_BISECT_B = 3,
+    IRON_PROF_SDF_GRAD = 4, IRON_PROF_MATERIAL = 5, IRON_PROF_GGX = 6, IRON_PROF_SDF_FORWARD = 7,
+    IRON_PROF_KINDS = 8
+};
+int iron_profile_enable(int32_t on);
+int iron_profile_read(double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

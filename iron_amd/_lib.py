@@ -49,7 +49,9 @@ class iron_shade_out(C.Structure):
                 ("specular_roughness", C.c_void_p), ("normal", C.c_void_p)]
 
 
-TRACE_STATS_FIELDS = ("n_evals", "n_sphere_conv", "n_sampler", "n_bisect", "n_conv", "r0", "r1", "r2")
+TRACE_STATS_FIELDS = ("n_evals", "n_sphere_conv", "n_sampler", "n_bisect", "n_conv", "n_evals_ref", "n_evals_sphere",
+                      "reserved")
+PROF_KINDS = ("sphere", "sampler", "bisect_a", "bisect_b", "sdf_grad", "material", "ggx", "sdf_forward")
 
 # every symbol include/iron_hip.h declares: name -> (restype, argtypes)
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -70,6 +72,8 @@ SYMBOLS = {
                              _P, _SZ, _P]),
     "iron_trace_phase": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _I64, _P,
                                    _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "iron_profile_enable": (C.c_int, [_I32]),
+    "iron_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
     "iron_shade_workspace_bytes": (_SZ, [_I64]),
     "iron_shade_ggx": (C.c_int, [C.POINTER(iron_shade_nets), _F, _I32, _P, _P, _P, _P, _P, _P, _I64,
                                  C.POINTER(iron_shade_out), _P, _SZ, _P]),
@@ -107,6 +111,18 @@ def check(status: int) -> None:
         if status == -3:
             msg += " [hipError_t=%d]" % lib.iron_last_hip_error()
         raise IronError("libiron_hip: %s" % msg)
+
+
+def profile_enable(on: bool) -> None:
+    check(load().iron_profile_enable(1 if on else 0))
+
+
+def profile_read() -> dict:
+    """{kernel kind: (milliseconds, launches)} accumulated since the last read (blocks on the events)."""
+    ms = (C.c_double * len(PROF_KINDS))()
+    cnt = (C.c_int64 * len(PROF_KINDS))()
+    check(load().iron_profile_read(ms, cnt))
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

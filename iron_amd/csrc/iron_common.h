@@ -96,6 +96,17 @@ inline int hip_fail(hipError_t e) {
 }
 }  // namespace iron
 
+namespace iron {
+// hipEvent pair around one kernel launch when profiling is enabled (profile.hip)
+void prof_begin(int kind, hipStream_t st);
+void prof_end(int kind, hipStream_t st);
+struct ProfScope {
+    int kind; hipStream_t st;
+    ProfScope(int k, hipStream_t s) : kind(k), st(s) { prof_begin(kind, st); }
+    ~ProfScope() { prof_end(kind, st); }
+};
+}  // namespace iron
+
 #define IRON_HIP_TRY(expr)                                  \
     do {                                                    \
         hipError_t _e = (expr);                             \

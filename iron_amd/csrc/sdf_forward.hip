@@ -76,6 +76,7 @@ extern "C" int iron_sdf_forward(const iron_net_t* net, const float* x, int64_t n
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_tiles = (n + kTile - 1) / kTile;
     if (((uintptr_t)x & 3) || ((uintptr_t)out & 3)) return IRON_ERR_BAD_ARG;
+    ProfScope ps(IRON_PROF_SDF_FORWARD, st);
     if (out_cols == 1) {
         hipLaunchKernelGGL(k_sdf_values, dim3(grid_for_tiles(n_tiles)), dim3(64), 0, st, net->sdf, x, n, out, 1);
     } else {

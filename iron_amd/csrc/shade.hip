@@ -386,6 +386,7 @@ static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_t
     }
     const int cus = cu_count();
     const unsigned grid = (unsigned)(max_tiles < cus ? (max_tiles > 0 ? max_tiles : 1) : cus);
+    ProfScope ps(IRON_PROF_SDF_GRAD, st);
     hipLaunchKernelGGL(k_sdf_grad, dim3(grid), dim3(256), lds_bytes, st, sdf->sdf, a);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
@@ -399,6 +400,7 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
     const iron_net_desc& d = net->desc;
     const int lp = d.multires > 0 ? d.multires : 0;
     const int lv = d.multires_view > 0 ? d.multires_view : 0;
+    ProfScope ps(IRON_PROF_MATERIAL, st);
     if (d.mode == IRON_MODE_IDR && lp == 0 && lv == 4) {
         hipLaunchKernelGGL((k_material<0, 4, true, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
@@ -510,6 +512,7 @@ extern "C" int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t 
     sa.raw_kd = kd; sa.raw_ks = ks; sa.raw_r = rr; sa.tab_trans = tab_trans; sa.tab_diff = tab_diff_trans;
     sa.light = light; sa.is_metal = is_metal; sa.out = *out;
     {
+        ProfScope ps(IRON_PROF_GGX, st);
         const int64_t b = (n + 255) / 256;
         hipLaunchKernelGGL(k_ggx_shade, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, st, sa);
     }

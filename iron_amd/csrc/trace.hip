@@ -34,7 +34,7 @@ struct TraceCounters {  // zeroed at the start of every call
     int pad[2];
     long long n_evals;
     long long n_sphere_conv;
-    long long n_conv_sampler;
+    long long n_evals_sphere;
     long long pad2;
 };
 
@@ -48,6 +48,8 @@ struct TraceWs {
     float* root_fhi;
     int* root_k;        // iterations done in phase A
     int* chunk_iters;   // [n_chunks]
+    int* chunk_roots;   // [n_chunks] bisected rays per chunk (for the reference-equivalent eval count)
+    int n_chunks;
 };
 
 struct TraceArgs {
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, Tr
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
     if (lane == 0) {
         atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
+        atomicAdd((unsigned long long*)&w.cnt->n_evals_sphere, (unsigned long long)evals);
         atomicAdd((unsigned long long*)&w.cnt->n_sphere_conv, (unsigned long long)c);
     }
 }
@@ -269,7 +272,9 @@ __global__ __launch_bounds__(64, 1) void k_bisect_a(SdfNetDev net, TraceArgs a, 
         if (valid && lane < 32) {
             w.root_lo[li] = lo; w.root_hi[li] = hi;
             w.root_k[li] = k;
-            if (k > 0) atomicMax(&w.chunk_iters[ray_chunk(a, ray)], k);
+            const long long ch = ray_chunk(a, ray);
+            atomicAdd(&w.chunk_roots[ch], 1);
+            if (k > 0) atomicMax(&w.chunk_iters[ch], k);
         }
     }
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
@@ -326,21 +331,25 @@ __global__ __launch_bounds__(64, 1) void k_bisect_b(SdfNetDev net, TraceArgs a, 
     }
 }
 
-__global__ void k_trace_stats(TraceWs w, iron_trace_stats* out) {
+__global__ void k_trace_stats(TraceWs w, int n_steps, iron_trace_stats* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         out->n_evals = w.cnt->n_evals;
         out->n_sphere_conv = w.cnt->n_sphere_conv;
         out->n_sampler = w.cnt->n_sampler;
         out->n_bisect = w.cnt->n_root;
         out->n_conv = w.cnt->n_sphere_conv + w.cnt->n_root;
-        out->reserved[0] = out->reserved[1] = out->reserved[2] = 0;
+        long long e = w.cnt->n_evals_sphere + (long long)w.cnt->n_sampler * n_steps;
+        for (int c = 0; c < w.n_chunks; ++c) e += (long long)w.chunk_roots[c] * (w.chunk_iters[c] + 1);
+        out->n_evals_ref = e;
+        out->n_evals_sphere = w.cnt->n_evals_sphere;
+        out->reserved = 0;
     }
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t cnt, sampler_list, root_list, lo, hi, flo, fhi, k, chunk_iters, total;
+    size_t cnt, sampler_list, root_list, lo, hi, flo, fhi, k, chunk_iters, chunk_roots, total;
     int64_t n_chunks;
 };
 
@@ -352,6 +361,7 @@ static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
     size_t o = 0;
     L.cnt = o; o += align256(sizeof(TraceCounters));
     L.chunk_iters = o; o += align256(sizeof(int) * (size_t)L.n_chunks);
+    L.chunk_roots = o; o += align256(sizeof(int) * (size_t)L.n_chunks);
     L.sampler_list = o; o += align256(sizeof(int) * nn);
     L.root_list = o; o += align256(sizeof(int) * nn);
     L.lo = o; o += align256(sizeof(float) * nn);
@@ -380,7 +390,8 @@ using namespace iron;
 
 extern "C" size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params* p) {
     if (n < 0) return 0;
-    return ws_layout(n, p).total;
+    // + room for a whole-image chunk table (multi-rank form): 64 Ki chunks
+    return ws_layout(n, p).total + align256(sizeof(int) * 65536);
 }
 
 extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps,
@@ -397,7 +408,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     const WsLayout L = ws_layout(n, p);
     if (workspace_bytes < L.total) return IRON_ERR_WORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
-    if (chunk_iters && n_chunks < 1) return IRON_ERR_BAD_ARG;
+    if (chunk_iters && (n_chunks < 1 || n_chunks > 65536)) return IRON_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
     TraceWs w;
@@ -410,6 +421,13 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     w.root_fhi = (float*)(base + L.fhi);
     w.root_k = (int*)(base + L.k);
     w.chunk_iters = chunk_iters ? chunk_iters : (int*)(base + L.chunk_iters);
+    w.chunk_roots = (int*)(base + L.chunk_roots);
+    w.n_chunks = (int)(chunk_iters ? n_chunks : L.n_chunks);
+    if (chunk_iters && n_chunks > L.n_chunks) {
+        // multi-rank: the chunk table covers the whole image, not just this rank's rays
+        if (workspace_bytes < L.total + align256(sizeof(int) * (size_t)n_chunks)) return IRON_ERR_WORKSPACE;
+        w.chunk_roots = (int*)(base + L.total);
+    }
     TraceArgs a;
     a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.work = work; a.ray_index = ray_index;
     a.lin = lin_steps; a.conv = conv; a.points = points; a.sdf = sdf_out; a.dist = dist;
@@ -420,14 +438,27 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, align256(sizeof(TraceCounters)), st));
         if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));
         else IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int) * (size_t)L.n_chunks), st));
+        IRON_HIP_TRY(hipMemsetAsync(w.chunk_roots, 0, sizeof(int) * (size_t)w.n_chunks, st));
         const int64_t tiles = (n + 31) / 32;
-        hipLaunchKernelGGL(k_sphere, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
-        hipLaunchKernelGGL(k_sampler, dim3((unsigned)(n < waves ? n : waves)), dim3(64), 0, st, sdf->sdf, a, w);
-        hipLaunchKernelGGL(k_bisect_a, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        {
+            ProfScope ps(IRON_PROF_SPHERE, st);
+            hipLaunchKernelGGL(k_sphere, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        }
+        {
+            ProfScope ps(IRON_PROF_SAMPLER, st);
+            hipLaunchKernelGGL(k_sampler, dim3((unsigned)(n < waves ? n : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        }
+        {
+            ProfScope ps(IRON_PROF_BISECT_A, st);
+            hipLaunchKernelGGL(k_bisect_a, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        }
     } else {
         const int64_t tiles = (n + 31) / 32;
-        hipLaunchKernelGGL(k_bisect_b, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
-        if (stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w, stats);
+        {
+            ProfScope ps(IRON_PROF_BISECT_B, st);
+            hipLaunchKernelGGL(k_bisect_b, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+        }
+        if (stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w, p->n_steps, stats);
     }
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;

@@ -99,6 +99,52 @@ class RayTracer(nn.Module):
         return {"convergent_mask": conv, "points": points, "sdf": sdf_out, "distance": dist}
 
 
+    @torch.no_grad()
+    def forward_phased(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, reduce_fn,
+                       collect_stats: bool = False):
+        """Multi-rank form of forward(): the rays of one reference chunk may live on several ranks, so the
+        chunk-global bisection count is exchanged between the two halves.  `ray_index` [n] int64 = position of
+        each ray in the whole job (chunk id = ray_index // chunk); `reduce_fn(int32[n_chunks])` must MAX-reduce
+        the table over the ranks in place (iron_amd.sharding.reduce_chunk_iters)."""
+        net = getattr(sdf, "sdf_network", None)
+        if net is None or not hasattr(net, "hip_net"):
+            raise _lib.IronError("forward_phased needs SDFHandle(sdf_network)")
+        o = _lib.require_cuda_f32(ray_o, "ray_o").reshape(-1, 3)
+        d = _lib.require_cuda_f32(ray_d, "ray_d").reshape(-1, 3)
+        near = _lib.require_cuda_f32(min_dis, "min_dis").reshape(-1)
+        far = _lib.require_cuda_f32(max_dis, "max_dis").reshape(-1)
+        work = work_mask.reshape(-1).contiguous()
+        idx = ray_index.reshape(-1).contiguous()
+        if idx.dtype != torch.int64 or not idx.is_cuda:
+            raise _lib.IronError("ray_index must be a CUDA int64 tensor")
+        n = o.shape[0]
+        dev = o.device
+        conv = torch.empty(n, dtype=torch.bool, device=dev)
+        points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        sdf_out = torch.empty(n, dtype=torch.float32, device=dev)
+        dist = torch.empty(n, dtype=torch.float32, device=dev)
+        chunk_iters = torch.zeros(int(n_chunks), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        prm = self._params(chunk)
+        ws_bytes = lib.iron_trace_workspace_bytes(n, C.byref(prm))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        stats = torch.zeros(8, dtype=torch.int64, device=dev) if collect_stats else None
+        lin = _linspace_steps(self.n_steps, dev)
+        args = (net.hip_net().handle, C.byref(prm), lin.data_ptr(), o.data_ptr(), d.data_ptr(), near.data_ptr(),
+                far.data_ptr(), work.data_ptr(), idx.data_ptr(), n, chunk_iters.data_ptr(), int(n_chunks),
+                conv.data_ptr(), points.data_ptr(), sdf_out.data_ptr(), dist.data_ptr(), _lib.ptr(stats),
+                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+        with torch.cuda.device(dev):
+            if n > 0:
+                _lib.check(lib.iron_trace_phase(0, *args))
+            reduce_fn(chunk_iters)
+            if n > 0:
+                _lib.check(lib.iron_trace_phase(1, *args))
+        if collect_stats:
+            self.last_stats = dict(zip(_lib.TRACE_STATS_FIELDS, stats.cpu().tolist()))
+        return {"convergent_mask": conv, "points": points, "sdf": sdf_out, "distance": dist}
+
+
 @torch.no_grad()
 def intersect_sphere(ray_o, ray_d, r):
     """raytracer.py:223-237 -> (mask bool[...], near[...], far[...])."""
