@@ -51,8 +51,15 @@ def cpu_baseline(scene: str, res: int):
     from oracle import iron_ref as R
     from iron_amd import scenes
     from _util import oracle_scene
-    threads = os.cpu_count() or 1
+    # the GPU box gives one job a 16-core share of a much larger host: size the pool to what we may use
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
+    print("[bench] cpu_baseline: oracle on %d threads (affinity %d, cpu_count %s)" % (threads, avail, os.cpu_count()),
+          file=sys.stderr, flush=True)
     sc = oracle_scene(scenes.build_networks(scene))
     K, W2C = scenes.fixture_camera_matrices(res, res)
     cam = R.CameraSpec(res, res, K, W2C)
@@ -115,6 +122,8 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    if rank == 0:
+        print("[bench] warmup done", file=sys.stderr, flush=True)
     _lib.profile_enable(True)
     _lib.profile_read()
     barrier()
@@ -127,6 +136,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.profile_enable(False)
+    if rank == 0:
+        print("[bench] timed region: %.3f s for %d steps" % (dt, a.steps), file=sys.stderr, flush=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -199,7 +210,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.scene, a.cpu_sample_res)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
