@@ -81,10 +81,17 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     import torch.distributed as dist
+    # IRON_BENCH_BACKEND=gloo + IRON_BENCH_ONE_GPU=1: rehearse the N>1 path with all ranks on one card
+    backend = os.environ.get("IRON_BENCH_BACKEND", "nccl")
+    one_gpu = os.environ.get("IRON_BENCH_ONE_GPU", "0") == "1"
+    dev_index = 0 if (world == 1 or one_gpu) else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from iron_amd import _lib, scenes
@@ -138,8 +145,9 @@ def main():
     _lib.profile_enable(False)
     if rank == 0:
         print("[bench] timed region: %.3f s for %d steps" % (dt, a.steps), file=sys.stderr, flush=True)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -148,7 +156,7 @@ def main():
     torch.cuda.synchronize()
     st = tracer.last_stats
     cnt = torch.tensor([st["n_evals_ref"], st["n_evals"], st["n_conv"], st["n_evals_sphere"], st["n_sampler"], st["n_bisect"]],
-                       dtype=torch.int64, device=dev)
+                       dtype=torch.int64, device=coll_dev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     E_ref, E_hip, H, E_sphere, n_sampler, n_bisect = [int(x) for x in cnt.tolist()]

@@ -54,10 +54,21 @@ def global_ray_index(pix: torch.Tensor, view: int, H: int, W: int, chunk: int) -
     return pix + view * chunks_per_view(H, W, chunk) * chunk
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """gloo has no device collectives for every op: stage device tensors through the host for it (tests /
+    rehearsals on one GPU); RCCL ("nccl") works on device buffers directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def reduce_chunk_iters(chunk_iters: torch.Tensor, group=None) -> torch.Tensor:
-    """MAX all-reduce of the per-chunk bisection counts (exchange 1)."""
+    """MAX all-reduce of the per-chunk bisection counts (exchange 1), in place."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(chunk_iters, op=dist.ReduceOp.MAX, group=group)
+        if _via_host(chunk_iters, group):
+            h = chunk_iters.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            chunk_iters.copy_(h)
+        else:
+            dist.all_reduce(chunk_iters, op=dist.ReduceOp.MAX, group=group)
     return chunk_iters
 
 
@@ -69,6 +80,9 @@ def gather_records(local: torch.Tensor, sizes: Sequence[int], group=None, dst: i
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_max = max(sizes)
+    dev = local.device
+    if _via_host(local, group):
+        local = local.cpu()
     buf = local
     if local.shape[0] != n_max:
         buf = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -77,7 +91,7 @@ def gather_records(local: torch.Tensor, sizes: Sequence[int], group=None, dst: i
     if rank == dst:
         outs = [torch.empty_like(buf) for _ in range(world)]
         dist.gather(buf, outs, dst=dst, group=group)
-        return [o[: sizes[r]] for r, o in enumerate(outs)]
+        return [o[: sizes[r]].to(dev) for r, o in enumerate(outs)]
     dist.gather(buf, None, dst=dst, group=group)
     return None
 
