@@ -1,0 +1,158 @@
+"""GPU: BASELINE.json's full size (800x800, config C1) through size-independent properties, plus the tracer's
+edge cases.  The oracle needs minutes at this size, so the checks are invariants of the algorithm and the
+oracle's committed work counts (tests/golden/work_counts.json, made by tools/count_work.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iron_ref as R
+from iron_amd import scenes
+from iron_amd.raytracer import Camera, RayTracer, SDFHandle, intersect_sphere, raytrace_camera, render_camera
+from iron_amd.renderer_ggx import GGXColocatedRenderer
+from iron_amd.rendering_func import make_render_fn
+
+from _util import GOLDEN, oracle_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frame800():
+    nets = {k: v.cuda() for k, v in scenes.build_networks("S0").items()}
+    K, W2C = scenes.fixture_camera_matrices(800, 800)
+    cam = Camera(800, 800, K.cuda(), W2C.cuda())
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    import iron_amd.raytracer as rt
+    tracer = RayTracer()
+    rt.VERBOSE_MODE = True
+    try:
+        res = render_camera(cam, nets["sdf_network"], tracer, nets, fn, fill_holes=False, handle_edges=False)
+    finally:
+        rt.VERBOSE_MODE = False
+    torch.cuda.synchronize()
+    return nets, cam, fn, res, tracer.last_stats
+
+
+def test_fullsize_work_counts_match_oracle(frame800):
+    """H (hits) and the reference-equivalent evaluation count E of the 800x800 frame vs the CPU oracle."""
+    _, _, _, res, st = frame800
+    wc = json.load(open(os.path.join(GOLDEN, "work_counts.json")))["S0_800"]
+    H = int(res["convergent_mask"].sum())
+    assert abs(H - wc["H"]) <= 8, (H, wc["H"])                       # a handful of silhouette flips at most
+    assert abs(st["n_evals_ref"] - wc["E"]) <= wc["E"] * 1e-4         # same algorithm, same work
+    assert st["n_evals"] <= st["n_evals_ref"]                          # early exit only removes work
+    assert abs(st["n_sampler"] - wc["n_sampler"]) <= 16
+
+
+def test_fullsize_invariants(frame800):
+    nets, cam, _, res, st = frame800
+    conv = res["convergent_mask"]
+    assert conv.shape == (800, 800) and conv.dtype == torch.bool
+    # every convergent ray sits on the zero level set to the tracer's tolerance: sphere-traced rays meet
+    # |sdf| <= 5e-5 (raytracer.py:128-133); bisected rays are inside a 1e-4 bracket (|sdf| <~ 1e-4 * |grad|)
+    s = res["sdf"][conv].abs()
+    assert float(s.max()) <= 2e-4
+    assert float((s <= 5e-5).float().mean()) >= 0.6
+    # re-evaluating the network at the returned points reproduces the returned sdf (same kernel: bitwise)
+    re = nets["sdf_network"].sdf(res["points"][conv])[:, 0]
+    assert torch.equal(re, res["sdf"][conv])
+    # points lie on their rays at the returned distance, inside the unit sphere
+    p = res["ray_o"] + res["ray_d"] * res["distance"].unsqueeze(-1)
+    assert float((p - res["points"])[conv].abs().max()) <= 2e-6
+    assert float(res["points"][conv].norm(dim=-1).max()) <= 1.0 + 1e-5
+    # depth = distance / |d| on hits, 0 elsewhere (raytracer.py:393,552)
+    assert torch.all(res["depth"][~conv] == 0)
+    np.testing.assert_allclose(res["depth"][conv].cpu().numpy(), (res["distance"] / res["ray_d_norm"])[conv].cpu().numpy(), rtol=1e-6)
+    # shading outputs: zero off the mask, finite and in range on it
+    for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "normal"):
+        assert torch.all(res[k][~conv] == 0), k
+        assert torch.isfinite(res[k]).all(), k
+    assert torch.all(res["specular_roughness"][~conv] == 0)
+    n = res["normal"][conv]
+    assert float((n.norm(dim=-1) - 1).abs().max()) <= 1e-5                       # render_surface.py:127
+    assert float(res["diffuse_albedo"][conv].min()) >= 0 and float(res["diffuse_albedo"][conv].max()) <= 1.0   # sigmoid
+    assert float(res["specular_roughness"][conv].min()) >= 0.01                  # rendering_func.py:11
+    sa = res["specular_albedo"][conv]
+    assert torch.equal(sa[:, 0], sa[:, 1]) and torch.equal(sa[:, 1], sa[:, 2])   # channel mean (is_metal=False)
+    col = res["color"][conv]
+    np.testing.assert_allclose(col.cpu().numpy(), (res["diffuse_color"] + res["specular_color"])[conv].cpu().numpy(), rtol=1e-6, atol=1e-8)
+    assert float(col.min()) >= 0
+
+
+def test_fullsize_deterministic_and_linear_in_light(frame800):
+    nets, cam, fn, res, _ = frame800
+    res2 = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=False, handle_edges=False)
+    for k in ("convergent_mask", "distance", "points", "color", "normal"):
+        assert torch.equal(res[k], res2[k]), k                                    # idempotent, bitwise
+    # GGX is linear in the light intensity (renderer_ggx.py:94): doubling the light doubles the colour exactly
+    old = float(nets["point_light_network"].get_light())
+    try:
+        nets["point_light_network"].set_light(2.0 * old)
+        res3 = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=False, handle_edges=False)
+    finally:
+        nets["point_light_network"].set_light(old)
+    assert torch.equal(res3["convergent_mask"], res["convergent_mask"])
+    np.testing.assert_allclose(res3["color"].cpu().numpy(), 2.0 * res["color"].cpu().numpy(), rtol=2e-6, atol=0)
+
+
+def test_chunk_global_bisection_semantics():
+    """Several reference chunks in one launch: rays of a chunk share the bisection count (raytracer.py:204-217).
+    Compared ray by ray with the oracle run chunk by chunk."""
+    nets = scenes.build_networks("S1")
+    sc = oracle_scene(nets)
+    sdf = nets["sdf_network"].cuda()
+    K, W2C = scenes.fixture_camera_matrices(56, 56)
+    cam = Camera(56, 56, K.cuda(), W2C.cuda())
+    for chunk in (500, 1000, 3136):
+        res = raytrace_camera(cam, sdf, RayTracer(), max_num_rays=chunk)
+        ref = R.raytrace_camera(sc, R.CameraSpec(56, 56, K, W2C), max_num_rays=chunk)
+        conv = res["convergent_mask"].cpu().numpy()
+        assert int((conv != ref["convergent_mask"].numpy()).sum()) <= 2
+        both = conv & ref["convergent_mask"].numpy()
+        d = np.abs(res["distance"].cpu().numpy() - ref["distance"].numpy())[both]
+        assert d.max() <= 2e-4
+        # bisected rays end inside the reference's final bracket width: the extra chunk-wide iterations are applied
+        assert np.percentile(d, 99) <= 5e-5
+
+
+def test_tracer_edge_cases():
+    nets = scenes.build_networks("S0")
+    sc = oracle_scene(nets)
+    sdf = nets["sdf_network"].cuda()
+    h = SDFHandle(sdf)
+    dev = "cuda"
+    # all rays miss the unit sphere: nothing converges, state = the single initial evaluation
+    o = torch.tensor([[0.0, 0.0, 3.0]], device=dev).repeat(70, 1)
+    d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.2, 0.0]], device=dev).repeat(70, 1), dim=-1)
+    m, near, far = intersect_sphere(o, d, 1.0)
+    assert not bool(m.any())
+    out = RayTracer()(h, o, d, near, far, m)
+    assert not bool(out["convergent_mask"].any())
+    ref = R.raytracer_forward(sc.sdf_fn, o.cpu(), d.cpu(), near.cpu(), far.cpu(), m.cpu())
+    np.testing.assert_allclose(out["sdf"].cpu().numpy(), ref["sdf"].numpy(), atol=5e-6)
+    np.testing.assert_allclose(out["distance"].cpu().numpy(), ref["distance"].numpy(), atol=1e-6)
+    # work mask all False although rays cross the object
+    o2 = torch.tensor([[0.0, 0.0, 2.0]], device=dev).repeat(33, 1)
+    d2 = torch.tensor([[0.0, 0.0, -1.0]], device=dev).repeat(33, 1)
+    m2, n2, f2 = intersect_sphere(o2, d2, 1.0)
+    out2 = RayTracer()(h, o2, d2, n2, f2, torch.zeros_like(m2))
+    assert not bool(out2["convergent_mask"].any())
+    # non-default tracer parameters (n_steps not a multiple of 32, fewer sphere-tracing iterations)
+    K, W2C = scenes.fixture_camera_matrices(40, 40)
+    cam = Camera(40, 40, K.cuda(), W2C.cuda())
+    for kw in (dict(n_steps=100, sphere_tracing_iters=4), dict(n_steps=33, sphere_tracing_iters=0),
+               dict(sdf_threshold=1e-3, n_steps=64)):
+        tr = RayTracer(**kw)
+        res = raytrace_camera(cam, sdf, tr, max_num_rays=50000)
+        prm = R.TracerParams(sdf_threshold=kw.get("sdf_threshold", 5e-5), sphere_tracing_iters=kw.get("sphere_tracing_iters", 16),
+                             n_steps=kw.get("n_steps", 128))
+        ref = R.raytrace_camera(sc, R.CameraSpec(40, 40, K, W2C), max_num_rays=50000, prm=prm)
+        conv = res["convergent_mask"].cpu().numpy()
+        assert int((conv != ref["convergent_mask"].numpy()).sum()) <= 2, kw
+        both = conv & ref["convergent_mask"].numpy()
+        if both.any():
+            tol = 2.5 * kw.get("sdf_threshold", 5e-5) + 1e-4
+            assert np.abs(res["distance"].cpu().numpy() - ref["distance"].numpy())[both].max() <= tol, kw
