@@ -77,6 +77,17 @@ struct RenderNetDev {
     float squeeze_out_scale, output_bias, output_scale;
 };
 
+// Packed weight stream of the h2 core (mlp_h2.h): the slot sequence the LDS ring walks.
+struct H2StreamDev {
+    const char* base;     // packed stream (global)
+    uint32_t table_off;   // byte offset (from base) of the slot table: uint2 {byte offset, kind(0 head | 1 hidden)}
+    uint32_t n_slots;     // sequence length
+    uint32_t bias_off;    // f32 bias blocks [layer][8][2][16]
+    uint32_t rows_off;    // f32 last-layer rows [3][8][2][16]
+    uint32_t n_bias_layers;
+    uint32_t kind_mask[4]; // bit q: slot q of the sequence is a hidden (32 KiB) slot, else a head (8 KiB) slot
+};
+
 }  // namespace iron
 
 struct iron_net {
@@ -85,6 +96,9 @@ struct iron_net {
     size_t blob_bytes;
     iron::SdfNetDev sdf;
     iron::RenderNetDev rnd;
+    void* h2_blob;        // h2 (split-fp16) stream, SDF nets
+    iron::H2StreamDev h2_trace;  // hidden stack only
+    iron::H2StreamDev h2_full;   // + the feature rows of the last layer
     int device;
 };
 

@@ -1,0 +1,401 @@
+// "h2" MLP core for gfx950: fp32-accurate dense layers on the f16 matrix pipe.
+//
+// Every fp32 operand is split into two fp16 pieces, x = xh + xl * 2^-11 (xh = f16(x), xl = f16((x - xh) * 2^11):
+// 22 mantissa bits, the low piece scaled so that it stays in fp16's normal range), and a product is taken as
+//      w*x ~= wh*xh  +  2^-11 * (wh*xl + wl*xh)
+// i.e. three v_mfma_f32_32x32x16_f16 per 16-deep k-step (the dropped wl*xl term is 2^-22 relative) with fp32
+// accumulation in two accumulators.  That is 3 x 32 cycles for 32x32x16 MACs against 8 x 64 cycles of
+// v_mfma_f32_32x32x2_f32: 5.3x the matrix rate of the exact-fp32 core (mlp_core.h) at ~fp32 accuracy
+// (measured against the reference in tests/ and DESIGN.md).
+//
+// At that rate weight fragments can no longer be streamed per wave from L2 (the chip's L2 bandwidth would be
+// the bound), so a workgroup = 4 waves (one per SIMD, 32 points each) shares ONE weight stream through an
+// LDS ring: 4 slots x 32 KiB filled by LDS-DMA (global_load_lds), three slots in flight ahead of the
+// consumers, one raw s_barrier + one counted s_waitcnt vmcnt per slot, and the stream keeps running across
+// evaluations (the slot sequence of a network is periodic), so there is no pipeline fill per evaluation.
+// Activations stay in registers exactly as in mlp_core.h: points on lanes, the MFMA C/D register order of one
+// layer is the B-operand k order of the next (weights are permuted at pack time).
+#pragma once
+#include "iron_common.h"
+#include "mlp_core.h"
+
+namespace iron {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+constexpr int kRingSlots = 4;
+constexpr int kSlotBytes = 32768;
+constexpr int kRingBytes = kRingSlots * kSlotBytes;
+constexpr int kRingAhead = 3;            // slots in flight ahead of the one being consumed
+constexpr int kLoadsPerSlot = 8;         // LDS-DMA instructions per wave and slot (head: 256 B each, hidden: 1 KiB each)
+constexpr float kLoScale = 2048.0f;
+constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr int kHeadSlots = 24;           // head inputs: 3 k-steps of 8 (lane-half 0 | 1 share a slot: sin | cos)
+constexpr int kHeadKSteps = 3;
+
+// LDS map of an h2 kernel (one dynamic array; byte offsets)
+constexpr int kLdsRing = 0;
+constexpr int kLdsBias = kRingBytes;                    // [9 layers][8 tiles][2 halves][16] f32 = 9 KiB
+constexpr int kLdsBiasBytes = 9 * 1024;
+constexpr int kLdsRows = kLdsBias + kLdsBiasBytes;      // [3 rows][8][2][16] f32 = 3 KiB (last-layer rows)
+constexpr int kLdsRowsBytes = 3 * 1024;
+constexpr int kLdsTable = kLdsRows + kLdsRowsBytes;     // slot table: uint2 {offset, kind} x 128
+constexpr int kLdsTableBytes = 1024;
+constexpr int kLdsMisc = kLdsTable + kLdsTableBytes;    // per-wave flags etc.
+constexpr int kLdsMiscBytes = 256;
+constexpr int kLdsH2Total = kLdsMisc + kLdsMiscBytes;   // 144 640 B
+
+__device__ __forceinline__ f32x16 mfma_h(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 pair -> packed (hi, scaled lo) fp16 pairs, as raw dwords
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const float r0 = (x0 - (float)h[0]) * kLoScale;
+    const float r1 = (x1 - (float)h[1]) * kLoScale;
+    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// one 32-feature register tile (f32, MFMA C/D order) -> the two k-step B fragments (regs 8s..8s+7), hi and lo
+struct TileFrag {
+    half8 h[2];
+    half8 l[2];
+};
+
+__device__ __forceinline__ void split8(const float* v, half8& h, half8& l) {
+    u32x4 hh, ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned a, b;
+        split2(v[2 * i], v[2 * i + 1], a, b);
+        hh[i] = a;
+        ll[i] = b;
+    }
+    h = __builtin_bit_cast(half8, hh);
+    l = __builtin_bit_cast(half8, ll);
+}
+
+__device__ __forceinline__ void split_tile(const f32x16& v, TileFrag& t) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float tmp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i] = v[8 * s + i];
+        split8(tmp, t.h[s], t.l[s]);
+    }
+}
+
+struct HeadFrag {
+    half8 h[kHeadKSteps];
+    half8 l[kHeadKSteps];
+};
+
+__device__ __forceinline__ void split_head(const float* slots /*[24]*/, HeadFrag& f) {
+#pragma unroll
+    for (int s = 0; s < kHeadKSteps; ++s) split8(slots + 8 * s, f.h[s], f.l[s]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The shared weight ring.  All four waves of the workgroup step through the slot sequence together.
+// Slot q of the (periodic) sequence lives in ring buffer q % 4.  Per step:
+//     ring.sync()      s_waitcnt vmcnt(16) (my 8 loads of this slot are the oldest outstanding; the 16 loads of
+//                      the two younger slots stay in flight)  +  s_barrier (everyone's loads of this slot have
+//                      landed AND everyone is done reading the previous slot)
+//     ring.step(...)   hands out (read pointer, DMA destination, DMA source) and advances
+// The DMA refill and the LDS reads of one step are issued from ONE function whose pointers are __restrict__:
+// hipcc otherwise orders every ds_read behind ALL pending LDS-DMA (it cannot see that they touch different ring
+// buffers) with an s_waitcnt vmcnt(0), which drains the prefetch.
+// ------------------------------------------------------------------------------------------------------
+struct RingStep {
+    const char* rd;     // LDS: the slot to consume
+    char* wr;           // LDS: buffer to refill (the one the previous slot occupied)
+    const char* src;    // global: source of the refill, already offset by this lane
+    bool hidden;        // kind of the slot being refilled
+};
+
+struct Ring {
+    const char* gbase;
+    char* lds;
+    unsigned long long mask_lo, mask_hi;  // bit q = 1: slot q is a hidden slot (32 KiB), 0: head slot (8 KiB)
+    int n_slots;
+    int q_issue;          // sequence index of the next slot to issue
+    uint32_t off_issue;   // its byte offset in the stream
+    int b_issue;          // ring buffer it goes to
+    int b_take;           // ring buffer of the next slot to consume
+    int wave, lane;
+
+    __device__ __forceinline__ bool kind_of(int q) const {
+        const unsigned long long w = q < 64 ? mask_lo : mask_hi;
+        return (w >> (q & 63)) & 1ull;
+    }
+    __device__ __forceinline__ RingStep step() {
+        RingStep s;
+        s.hidden = kind_of(q_issue);
+        s.src = gbase + off_issue + (s.hidden ? lane * 16 : lane * 4);
+        s.wr = lds + kLdsRing + b_issue * kSlotBytes;
+        s.rd = lds + kLdsRing + b_take * kSlotBytes;
+        off_issue += s.hidden ? (uint32_t)kSlotBytes : 8192u;
+        if (++q_issue == n_slots) { q_issue = 0; off_issue = 0; }
+        b_issue = (b_issue + 1) & (kRingSlots - 1);
+        b_take = (b_take + 1) & (kRingSlots - 1);
+        return s;
+    }
+    __device__ __forceinline__ void sync() {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // before the kernel ends: no DMA may still be writing this workgroup's LDS
+    __device__ __forceinline__ void drain() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+};
+
+// this wave's 8 LDS-DMA instructions of one slot
+__device__ __forceinline__ void dma_issue(const char* src, char* __restrict__ wr, bool hidden, int wave) {
+#ifdef IRON_H2_NO_DMA  // timing experiment only: results are garbage
+    return;
+#endif
+    if (hidden) {  // 32 fragments of 1 KiB; this wave moves fragments wave, wave+4, ...
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            const int f = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+                                             (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+        }
+    } else {       // head slot: 8 KiB as 32 pieces of 256 B
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            const int f = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 256),
+                                             (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void ring_start(Ring& r, const H2StreamDev& s, char* lds_base, int wave, int lane) {
+    r.gbase = s.base; r.lds = lds_base; r.n_slots = (int)s.n_slots;
+    r.mask_lo = (unsigned long long)s.kind_mask[0] | ((unsigned long long)s.kind_mask[1] << 32);
+    r.mask_hi = (unsigned long long)s.kind_mask[2] | ((unsigned long long)s.kind_mask[3] << 32);
+    r.q_issue = 0; r.off_issue = 0; r.b_issue = 0; r.b_take = 0; r.wave = wave; r.lane = lane;
+    for (int i = 0; i < kRingAhead; ++i) {
+        RingStep st = r.step();
+        dma_issue(st.src, st.wr, st.hidden, wave);
+    }
+    r.b_take = 0;  // nothing consumed yet
+}
+
+// bias / output-row tiles live in LDS as f32 [tile][half][16]
+__device__ __forceinline__ f32x16 lds_half_tile(const char* __restrict__ lds_block, int tile, int half) {
+    const float4* p = reinterpret_cast<const float4*>(lds_block + (tile * 2 + half) * 64);
+    const float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    f32x16 v;
+    v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w;
+    v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+    v[8] = b2.x; v[9] = b2.y; v[10] = b2.z; v[11] = b2.w;
+    v[12] = b3.x; v[13] = b3.y; v[14] = b3.z; v[15] = b3.w;
+    return v;
+}
+
+__device__ __forceinline__ half8 lds_frag(const char* __restrict__ slot, int frag, int lane) {
+    return *reinterpret_cast<const half8*>(slot + frag * 1024 + lane * 16);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+    return v;
+}
+
+__device__ __forceinline__ f32x16 h2_combine(const f32x16& hi, const f32x16& lo) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = fmaf(lo[i], kLoInv, hi[i]);
+    return z;
+}
+
+// Scheduling recipe of a ring step (one scheduling region between two s_barriers): LDS fragment reads run one
+// k-step ahead of the MFMAs that consume them, and the VALU epilogue of the PREVIOUS output tile (combine,
+// softplus, fp16 split: ~15 VALU per k-step) is spread between the MFMAs, which execute asynchronously.
+// mask values (LLVM SchedGroupMask): VALU 0x2, MFMA 0x8, DS_READ 0x100.
+#ifndef IRON_H2_STEP_MASK
+#define IRON_H2_STEP_MASK 0x4  // only SALU may cross a k-step boundary: keeps each step's reads / MFMAs / VALU slice together
+#endif
+
+// One ring step on a head slot: fragments [k-step 0..2][piece hi, lo] (+ padding)
+__device__ __forceinline__ void step_head(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
+                                          const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
+                                          const HeadFrag& hd, f32x16& acc_hi, f32x16& acc_lo) {
+    dma_issue(src, wr, src_hidden, wave);
+    if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < kHeadKSteps; ++ks) {
+        const half8 wh = lds_frag(rd, 2 * ks, lane);
+        const half8 wl = lds_frag(rd, 2 * ks + 1, lane);
+        acc_hi = mfma_h(wh, hd.h[ks], acc_hi);
+        acc_lo = mfma_h(wh, hd.l[ks], acc_lo);
+        acc_lo = mfma_h(wl, hd.h[ks], acc_lo);
+    }
+}
+
+// epilogue of one output tile: z = hi + lo * 2^-11, activation, split into next-layer B fragments
+template <bool FAST>
+__device__ __forceinline__ void h2_epilogue_split(const f32x16& hi, const f32x16& lo, TileFrag& out) {
+    split_tile(softplus_tile<FAST>(h2_combine(hi, lo)), out);
+}
+
+// One ring step on a hidden slot, fused with the epilogue of the previous output tile:
+//   refill `wr`;  acc += W[tile,:] * in  (48 MFMAs, fragment reads one k-step ahead);  meanwhile (VALU) the pending
+//   accumulators `p_hi/p_lo` of tile-1 go through combine + softplus (+ fp16 split) into out_prev / hf_prev.
+// EPI: 0 = nothing pending, 1 = pending tile -> split fragments, 2 = pending tile -> f32 tile (last layer).
+// rd / bias / wr are distinct LDS regions (see the note above): __restrict__ is what lets the reads proceed
+// while the refill is in flight.
+template <bool FAST, int EPI>
+__device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
+                                            const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
+                                            const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
+                                            const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev) {
+    dma_issue(src, wr, src_hidden, wave);
+    if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
+    half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
+    float act[16];   // activated pending tile, produced one element per k-step
+    u32x4 oh[2], ol[2];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        half8 nh = fh, nl = fl;
+        if (ks < 15) {  // next k-step's fragments: in flight while this step's MFMAs run
+            nh = lds_frag(rd, 2 * ks + 2, lane);
+            nl = lds_frag(rd, 2 * ks + 3, lane);
+        }
+        const int ti = ks >> 1, s = ks & 1;
+        acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
+        acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
+        acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
+        fh = nh;
+        fl = nl;
+        // VALU slice of the previous tile's epilogue, placed in program order behind this k-step's MFMAs (they
+        // execute asynchronously): element ks -> combine + softplus; every second k-step one fp16 pair is split.
+        if constexpr (EPI != 0) {
+            act[ks] = softplus100<FAST>(fmaf(p_lo[ks], kLoInv, p_hi[ks]));
+            if constexpr (EPI == 1) {
+                if (ks & 1) {
+                    unsigned a, b2;
+                    split2(act[ks - 1], act[ks], a, b2);
+                    oh[ks >> 3][(ks >> 1) & 3] = a;
+                    ol[ks >> 3][(ks >> 1) & 3] = b2;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(IRON_H2_STEP_MASK);
+    }
+    if constexpr (EPI == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            out_prev.h[s2] = __builtin_bit_cast(half8, oh[s2]);
+            out_prev.l[s2] = __builtin_bit_cast(half8, ol[s2]);
+            // pin to this step (LLVM would otherwise sink the whole epilogue to the end of the layer)
+            asm volatile("" ::"v"(oh[s2]), "v"(ol[s2]));
+        }
+    }
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hf_prev[i] = act[i];
+        asm volatile("" ::"v"(hf_prev));
+    }
+}
+
+// One 256 -> 256 layer on the ring.  HEAD: the layer also has a head product (skip layer); LAST: the result is
+// delivered as f32 tiles in `hf` instead of split fragments in `out`.
+template <bool FAST, bool HEAD, bool LAST>
+__device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, const HeadFrag& hd, int lane,
+                                                const TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
+                                                f32x16 (&hf)[kHidTiles]) {
+    const int wave = ring.wave;
+    f32x16 acc[2][2];  // [tile parity][hi, lo]: the epilogue of tile t-1 overlaps the MFMAs of tile t
+    TileFrag dummy_out;
+    f32x16 dummy_hf;
+#define IRON_H2_TILE(TO)                                                                                                   \
+    {                                                                                                                      \
+        constexpr int P = (TO) & 1, Q = P ^ 1;                                                                             \
+        acc[P][0] = zero16();                                                                                              \
+        acc[P][1] = zero16();                                                                                              \
+        if constexpr (HEAD) {                                                                                              \
+            ring.sync();                                                                                                   \
+            const RingStep sh = ring.step();                                                                               \
+            step_head(sh.rd, bias, sh.wr, sh.src, sh.hidden, wave, lane, TO, true, hd, acc[P][0], acc[P][1]);              \
+        }                                                                                                                  \
+        ring.sync();                                                                                                       \
+        const RingStep st = ring.step();                                                                                   \
+        if constexpr ((TO) == 0)                                                                                           \
+            step_hidden<FAST, 0>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+                                 acc[Q][0], acc[Q][1], dummy_out, dummy_hf);                                               \
+        else if constexpr (LAST)                                                                                           \
+            step_hidden<FAST, 2>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+                                 acc[Q][0], acc[Q][1], dummy_out, hf[(TO) > 0 ? (TO) - 1 : 0]);                            \
+        else                                                                                                               \
+            step_hidden<FAST, 1>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+                                 acc[Q][0], acc[Q][1], out[(TO) > 0 ? (TO) - 1 : 0], dummy_hf);                            \
+    }
+    IRON_H2_TILE(0) IRON_H2_TILE(1) IRON_H2_TILE(2) IRON_H2_TILE(3)
+    IRON_H2_TILE(4) IRON_H2_TILE(5) IRON_H2_TILE(6) IRON_H2_TILE(7)
+#undef IRON_H2_TILE
+    if constexpr (LAST) hf[kHidTiles - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
+    else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[kHidTiles - 1]);
+}
+
+// dot of this lane's 128 resident f32 features with a row held in LDS ([8][2][16] f32), summed over the halves
+__device__ __forceinline__ float row_dot_lds(const char* __restrict__ row, const f32x16 (&h)[kHidTiles], int half) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t) {
+        const f32x16 w = lds_half_tile(row, t, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s = fmaf(w[r], h[t][r], s);
+    }
+    return s + __shfl_xor(s, 32, 64);
+}
+
+// SDFNetwork hidden stack on the h2 core.  All four waves of the workgroup must call it together.
+// On return hf (f32 tiles) holds the last hidden activation.
+template <bool FAST>
+__device__ __forceinline__ void sdf_hidden_stack_h2(Ring& ring, const char* lds, int n_hidden_layers, int skip_layer,
+                                                    float scale, float x, float y, float z, int lane,
+                                                    f32x16 (&hf)[kHidTiles]) {
+    const int half = lane >> 5;
+    const int wave = ring.wave;
+    float pe[kHeadSlots];
+#pragma unroll
+    for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
+    head_fill<kSdfPeLevels>(x * scale, y * scale, z * scale, half, pe);
+    HeadFrag hd;
+    split_head(pe, hd);
+
+    TileFrag in[kHidTiles], out[kHidTiles];
+    // layer 0: head only (9 MFMAs per tile: epilogue in place)
+#pragma unroll
+    for (int to = 0; to < kHidTiles; ++to) {
+        ring.sync();
+        const RingStep st = ring.step();
+        f32x16 a_hi = zero16(), a_lo = zero16();
+        step_head(st.rd, lds + kLdsBias, st.wr, st.src, st.hidden, wave, lane, to, true, hd, a_hi, a_lo);
+        h2_epilogue_split<FAST>(a_hi, a_lo, out[to]);
+    }
+    for (int l = 1; l < n_hidden_layers; ++l) {
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
+        const char* bias = lds + kLdsBias + l * 1024;
+        if (l == n_hidden_layers - 1) h2_hidden_layer<FAST, false, true>(ring, bias, hd, lane, in, out, hf);
+        else if (l == skip_layer) h2_hidden_layer<FAST, true, false>(ring, bias, hd, lane, in, out, hf);
+        else h2_hidden_layer<FAST, false, false>(ring, bias, hd, lane, in, out, hf);
+    }
+}
+
+}  // namespace iron

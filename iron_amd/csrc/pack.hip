@@ -4,6 +4,7 @@
 #include <string.h>
 #include <new>
 #include "iron_common.h"
+#include "pack_common.h"
 
 namespace iron {
 
@@ -28,15 +29,6 @@ __global__ void k_row_scale(const float* __restrict__ v, const float* __restrict
     if (threadIdx.x == 0) scale[o] = g[o] / sqrtf(s);
 }
 
-struct PackSrc {
-    const float* w;      // [rows, ld] row-major weight_v
-    const float* scale;  // per-row fold factor
-    int ld;
-    int rows_valid;      // rows >= this are zero padding
-    int row_off;         // first source row
-    float mul;           // extra factor (1/sqrt(2) for the skip layer)
-};
-
 // dst [pairs][8][4][2][64] float4 : lane (i,h) of (pair p, which w, in-tile ti, quad q) holds
 //   W[32*(2p+w) + i][col_off + 32*ti + 8*q + 4*h + 0..3]
 __global__ void k_pack_hidden(float4* __restrict__ dst, PackSrc s, int col_off, int cols_valid) {
@@ -60,13 +52,6 @@ __global__ void k_pack_hidden(float4* __restrict__ dst, PackSrc s, int col_off, 
     }
     dst[e] = make_float4(v[0], v[1], v[2], v[3]);
 }
-
-struct HeadSrcs {
-    int n;
-    int slot_base[3];
-    int levels[3];
-    int col_off[3];
-};
 
 // dst [pairs][NQ][2][64] float4 : lane (i,h) of (pair, quad q, which w) holds the weights of head
 // slots 4q..4q+3 (their lane-half-h columns) for output row 32*(2p+w)+i
@@ -168,12 +153,6 @@ int fold_scales(const iron_linear* L, int nl, float* scale_base, size_t* scale_o
     return IRON_OK;
 }
 
-inline PackSrc make_src(const iron_linear& l, const float* scale, int rows_valid, int row_off, float mul) {
-    PackSrc s;
-    s.w = l.weight_v; s.scale = scale; s.ld = l.in_dim; s.rows_valid = rows_valid; s.row_off = row_off; s.mul = mul;
-    return s;
-}
-
 inline void launch_pack_hidden(float4* dst, const PackSrc& s, int col_off, int cols_valid, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_hidden, dim3(kF4PerHidLayer / 256), dim3(256), 0, st, dst, s, col_off, cols_valid);
 }
@@ -188,7 +167,6 @@ inline void launch_pack_row(float4* dst, const PackSrc& s, int row, int col_off,
     hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)dst, s, row, col_off, cols_valid);
 }
 
-const float kInvSqrt2 = 1.0f / 1.41421356237309504880f;  // activations / np.sqrt(2) folded into W
 
 int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
     const iron_net_desc& d = net->desc;
@@ -233,7 +211,7 @@ int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
     memset(&hs, 0, sizeof(hs));
     hs.n = 1; hs.slot_base[0] = 0; hs.levels[0] = d.multires; hs.col_off[0] = 0;
     // layer 0
-    launch_pack_head(base + o_pe0, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
+    launch_pack_head(base + o_pe0, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
     launch_pack_bias(base + o_bias, L[0].bias, 0, L[0].out_dim, st);
     // hidden layers 1..nl-2
     for (int l = 1; l <= nl - 2; ++l) {
@@ -241,19 +219,19 @@ int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
         const float mul = is_skip ? kInvSqrt2 : 1.0f;
         const int cols_valid = is_skip ? kHidden - pe : kHidden;
         launch_pack_hidden(base + o_hid + (size_t)(l - 1) * kF4PerHidLayer,
-                           make_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), 0, cols_valid, st);
+                           make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), 0, cols_valid, st);
         launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, L[l].out_dim, st);
         if (is_skip) {
             HeadSrcs h2 = hs;
             h2.col_off[0] = kHidden - pe;
-            launch_pack_head(base + o_pes, make_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, nq, st);
+            launch_pack_head(base + o_pes, make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, nq, st);
         }
     }
     // last layer: row 0 = sdf, rows 1.. = feature
     const iron_linear& last = L[nl - 1];
-    launch_pack_row(base + o_last, make_src(last, scale_base + soff[nl - 1], 1, 0, 1.0f), 0, 0, kHidden, st);
+    launch_pack_row(base + o_last, make_pack_src(last, scale_base + soff[nl - 1], 1, 0, 1.0f), 0, 0, kHidden, st);
     if (d.d_out == kHidden + 1) {
-        launch_pack_hidden(base + o_feat, make_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), 0, kHidden, st);
+        launch_pack_hidden(base + o_feat, make_pack_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), 0, kHidden, st);
         launch_pack_bias(base + o_bfeat, last.bias, 1, kHidden, st);
     }
     IRON_HIP_TRY(hipGetLastError());
@@ -275,7 +253,7 @@ int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
     s.scale = d.scale;
     s.n_hidden_layers = nl - 1;
     s.skip_layer = skip;
-    return IRON_OK;
+    return build_h2_sdf(net, L, scale_base, soff, st);
 }
 
 int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
@@ -335,17 +313,17 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     int rc = fold_scales(L, nl, scale_base, soff, st);
     if (rc != IRON_OK) return rc;
 
-    launch_pack_head(base + o_head, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
-    launch_pack_hidden(base + o_feat0, make_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), head_w, kHidden, st);
+    launch_pack_head(base + o_head, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
+    launch_pack_hidden(base + o_feat0, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), head_w, kHidden, st);
     launch_pack_bias(base + o_bias, L[0].bias, 0, kHidden, st);
     for (int l = 1; l <= nl - 2; ++l) {
         launch_pack_hidden(base + o_hid + (size_t)(l - 1) * kF4PerHidLayer,
-                           make_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), 0, kHidden, st);
+                           make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), 0, kHidden, st);
         launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, kHidden, st);
     }
     const iron_linear& last = L[nl - 1];
     for (int o = 0; o < d.d_out; ++o)
-        launch_pack_row(base + o_last + (size_t)o * kF4PerBiasLayer, make_src(last, scale_base + soff[nl - 1], d.d_out, 0, 1.0f),
+        launch_pack_row(base + o_last + (size_t)o * kF4PerBiasLayer, make_pack_src(last, scale_base + soff[nl - 1], d.d_out, 0, 1.0f),
                         o, 0, kHidden, st);
     IRON_HIP_TRY(hipGetLastError());
     float bl[3] = {0, 0, 0};
@@ -389,6 +367,7 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
     else rc = IRON_ERR_UNSUPPORTED;
     if (rc != IRON_OK) {
         if (net->blob) (void)hipFree(net->blob);
+        if (net->h2_blob) (void)hipFree(net->h2_blob);
         delete net;
         return rc;
     }
@@ -399,6 +378,7 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
 extern "C" int iron_net_destroy(iron_net_t* net) {
     if (!net) return IRON_OK;
     if (net->blob) IRON_HIP_TRY(hipFree(net->blob));
+    if (net->h2_blob) IRON_HIP_TRY(hipFree(net->h2_blob));
     delete net;
     return IRON_OK;
 }

@@ -1,0 +1,140 @@
+// Packing for the h2 core (mlp_h2.h): folded fp32 weights -> split fp16 A-fragments of
+// v_mfma_f32_32x32x16_f16, laid out as the linear slot sequence the LDS ring streams.
+#include <string.h>
+#include <vector>
+#include "mlp_h2.h"
+#include "pack_common.h"
+
+namespace iron {
+
+// element j of lane (i, h) in the fragment of k-step ks (input tile ti = ks>>1, sub-step s = ks&1) multiplies
+// input feature 32*ti + 16*s + 8*(j>>2) + 4*h + (j&3): the order in which the previous layer's accumulator
+// registers 8s..8s+7 are handed over as the B operand.
+__device__ __forceinline__ void store_split(_Float16* dst_hi, _Float16* dst_lo, float w) {
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)((w - (float)hi) * kLoScale);
+    *dst_hi = hi;
+    *dst_lo = lo;
+}
+
+// dst: one hidden slot (32 KiB): fragments [ks 0..15][piece 0..1][lane 64][j 8] of fp16
+__global__ void k_pack_h2_hidden(_Float16* __restrict__ dst, PackSrc s, int to, int col_off, int cols_valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
+    if (e >= 16 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * to + i;
+    const int col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+    float w = 0.0f;
+    if (row < s.rows_valid && col < cols_valid)
+        w = s.w[(size_t)(s.row_off + row) * s.ld + col_off + col] * s.scale[s.row_off + row] * s.mul;
+    store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
+}
+
+// dst: one head slot (8 KiB): fragments [ks 0..2][piece][lane][j] + 2 KiB of zero padding
+__global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs hs, int to) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks 0..3, lane, j)
+    if (e >= 4 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * to + i;
+    float w = 0.0f;
+    if (ks < kHeadKSteps) {
+        const int slot = 8 * ks + j;
+        for (int k = 0; k < hs.n; ++k) {
+            const int local = slot - hs.slot_base[k];
+            if (local >= 0 && local < head_slots(hs.levels[k])) {
+                const int col = head_slot_column(local, h, hs.levels[k]);
+                if (col >= 0 && row < s.rows_valid)
+                    w = s.w[(size_t)(s.row_off + row) * s.ld + hs.col_off[k] + col] * s.scale[s.row_off + row] * s.mul;
+            }
+        }
+    }
+    store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
+}
+
+}  // namespace iron
+
+using namespace iron;
+
+namespace iron {
+
+// Builds the h2 stream of an SDF network next to its fp32 pack.  Slot sequence (= memory order):
+//   layer 0: 8 head slots; layers 1..n-2: per output tile [head slot if skip layer] hidden slot;
+//   then (full stream only) the 8 hidden slots of the feature rows of the last layer.
+int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int nl = d.n_linear;
+    const int skip = d.skip_layer;
+    const int pe = pe_width(d.multires);
+    const bool has_feat = d.d_out == kHidden + 1;
+    const int head_bytes = 8192, hid_bytes = kSlotBytes;
+    std::vector<uint32_t> table;  // {offset, kind} pairs
+    size_t off = 0;
+    auto add = [&](int kind) { table.push_back((uint32_t)off); table.push_back((uint32_t)kind); off += kind ? hid_bytes : head_bytes; };
+    for (int to = 0; to < kHidTiles; ++to) add(0);
+    for (int l = 1; l <= nl - 2; ++l)
+        for (int to = 0; to < kHidTiles; ++to) { if (l == skip) add(0); add(1); }
+    const uint32_t n_trace = (uint32_t)(table.size() / 2);
+    if (has_feat) for (int to = 0; to < kHidTiles; ++to) add(1);
+    const uint32_t n_full = (uint32_t)(table.size() / 2);
+    if (n_full > 127) return IRON_ERR_UNSUPPORTED;
+    const size_t data_bytes = off;
+    const size_t table_off = (data_bytes + 255) & ~(size_t)255;
+    const size_t bias_off = table_off + 1024;
+    const size_t rows_off = bias_off + kLdsBiasBytes;
+    const size_t total = rows_off + kLdsRowsBytes + 65536;  // tail padding: the ring may prefetch past the end
+    IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
+    IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
+    char* base = (char*)net->h2_blob;
+    IRON_HIP_TRY(hipMemcpyAsync(base + table_off, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    IRON_HIP_TRY(hipStreamSynchronize(st));  // `table` is host memory going out of scope
+
+    HeadSrcs hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.n = 1; hs.slot_base[0] = 0; hs.levels[0] = d.multires; hs.col_off[0] = 0;
+    size_t q = 0;
+    auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
+    for (int to = 0; to < kHidTiles; ++to, ++q)
+        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to);
+    for (int l = 1; l <= nl - 2; ++l) {
+        const bool is_skip = (l == skip);
+        const float mul = is_skip ? kInvSqrt2 : 1.0f;
+        const int cols_valid = is_skip ? kHidden - pe : kHidden;
+        for (int to = 0; to < kHidTiles; ++to) {
+            if (is_skip) {
+                HeadSrcs h2 = hs;
+                h2.col_off[0] = kHidden - pe;
+                hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, to);
+                ++q;
+            }
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), to, 0, cols_valid);
+            ++q;
+        }
+    }
+    const iron_linear& last = L[nl - 1];
+    if (has_feat)
+        for (int to = 0; to < kHidTiles; ++to, ++q)
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), to, 0, kHidden);
+    // f32 side blocks: biases of layers 0..nl-2 (+ feature bias as block nl-1), last-layer row 0
+    for (int l = 0; l <= nl - 2; ++l)
+        hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, L[l].out_dim);
+    if (has_feat)
+        hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)(nl - 1) * 1024), last.bias, 1, kHidden);
+    hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)(base + rows_off), make_pack_src(last, scale_base + soff[nl - 1], 1, 0, 1.0f), 0, 0, kHidden);
+    IRON_HIP_TRY(hipGetLastError());
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+
+    H2StreamDev s;
+    s.base = base; s.table_off = (uint32_t)table_off; s.n_slots = n_trace; s.bias_off = (uint32_t)bias_off;
+    s.rows_off = (uint32_t)rows_off; s.n_bias_layers = (uint32_t)nl;
+    for (int i = 0; i < 4; ++i) s.kind_mask[i] = 0;
+    for (size_t k = 0; k < table.size() / 2; ++k)
+        if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
+    net->h2_trace = s;
+    s.n_slots = n_full;
+    net->h2_full = s;
+    return IRON_OK;
+}
+
+}  // namespace iron

@@ -14,8 +14,9 @@
 //   k_bisect_b the reference loops while ANY ray of the call is unfinished and updates ALL rays, so
 //              every ray runs the chunk-wide maximum count: finish the remaining iterations, then
 //              the final mid-point evaluation.
-#include "mlp_core.h"
+#include "mlp_h2.h"
 #include "ggx_core.h"
+#include "h2_setup.h"
 
 namespace iron {
 
@@ -73,11 +74,67 @@ struct TraceArgs {
 
 __device__ __forceinline__ int lane_rank(unsigned mask, int j) { return __popc(mask & ((1u << j) - 1u)); }
 
-__global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, TraceWs w) {
-    const int lane = threadIdx.x;
-    const int j = lane & 31;
+// ---- evaluation back ends ---------------------------------------------------------------------------------
+// The tracer kernels are written once as per-wave state machines around three calls:
+//   be.any(p)   workgroup-wide OR of a wave-uniform predicate (decides whether another evaluation pass runs)
+//   be.eval()   SDF of the point on lane&31 -- collective over the workgroup
+//   be.finish()
+// BackendF32: one wave per workgroup, exact-fp32 MFMA core (mlp_core.h), weights streamed per wave from L2.
+// BackendH2 : four waves per workgroup in lock step on the split-fp16 core (mlp_h2.h) sharing the LDS ring.
+struct BackendF32 {
+    static constexpr int kThreads = 64;
+    SdfNetDev net;
     WStream ws;
-    ws.init(net.blob, net.blob_bytes, lane);
+    int lane;
+    __device__ __forceinline__ void init(const SdfNetDev& n, const H2StreamDev&, const H2Meta&) {
+        net = n;
+        lane = threadIdx.x;
+        ws.init(net.blob, net.blob_bytes, lane);
+    }
+    __device__ __forceinline__ bool any(bool p) { return p; }
+    __device__ __forceinline__ float eval(float x, float y, float z) { return sdf_eval<kFastActT>(net, ws, x, y, z, lane); }
+    __device__ __forceinline__ void finish() {}
+};
+
+struct BackendH2 {
+    static constexpr int kThreads = 256;
+    Ring ring;
+    char* lds;
+    H2Meta m;
+    int lane, wave, parity;
+    __device__ __forceinline__ void init(const SdfNetDev&, const H2StreamDev& s, const H2Meta& meta) {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        lds = smem;
+        m = meta;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        parity = 0;
+        h2_setup(s, lds, ring);
+    }
+    __device__ __forceinline__ bool any(bool p) {
+        volatile int* f = reinterpret_cast<volatile int*>(lds + kLdsMisc) + parity * 4;
+        if (lane == 0) f[wave] = p ? 1 : 0;
+        __syncthreads();
+        const int r = f[0] | f[1] | f[2] | f[3];
+        parity ^= 1;
+        return r != 0;
+    }
+    __device__ __forceinline__ float eval(float x, float y, float z) {
+        f32x16 hf[kHidTiles];
+        sdf_hidden_stack_h2<kFastActT>(ring, lds, m.n_hidden_layers, m.skip_layer, m.scale, x, y, z, lane, hf);
+        return (row_dot_lds(lds + kLdsRows, hf, lane >> 5) + m.b_last) / m.scale;
+    }
+    __device__ __forceinline__ void finish() { ring.drain(); }
+};
+
+#define IRON_TRACE_KERNEL_ARGS SdfNetDev net, H2StreamDev hs, H2Meta hm, TraceArgs a, TraceWs w
+
+template <class BE>
+__global__ __launch_bounds__(BE::kThreads, 1) void k_sphere(IRON_TRACE_KERNEL_ARGS) {
+    BE be;
+    be.init(net, hs, hm);
+    const int lane = be.lane;
+    const int j = lane & 31;
 
     bool active = false, unf = false, work = false, exhausted = false;
     int ray = 0, steps = 0;
@@ -110,10 +167,10 @@ __global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, Tr
             }
         }
         const unsigned act2 = (unsigned)__ballot(active);
-        if (act2 == 0u) break;
+        if (!be.any(act2 != 0u)) break;
         evals += __popc(act2);
 
-        const float s = sdf_eval<kFastActT>(net, ws, px, py, pz, lane);
+        const float s = be.eval(px, py, pz);
 
         bool retire = false, to_sampler = false;
         if (active) {
@@ -147,7 +204,7 @@ __global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, Tr
             px = py = pz = 0.f;
         }
     }
-    // per-wave stats
+    be.finish();
     long long c = nconv;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
@@ -158,39 +215,49 @@ __global__ __launch_bounds__(64, 1) void k_sphere(SdfNetDev net, TraceArgs a, Tr
     }
 }
 
-__global__ __launch_bounds__(64, 1) void k_sampler(SdfNetDev net, TraceArgs a, TraceWs w) {
-    const int lane = threadIdx.x;
+template <class BE>
+__global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_ARGS) {
+    BE be;
+    be.init(net, hs, hm);
+    const int lane = be.lane;
     const int j = lane & 31;
-    WStream ws;
-    ws.init(net.blob, net.blob_bytes, lane);
     const int n_list = w.cnt->n_sampler;
     long long evals = 0;
+    bool has_ray = false, exhausted = false;
+    int ray = 0, blk = 0;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, smin = 0.f, width = 0.f, prev_z = 0.f, prev_f = 0.f;
     for (;;) {
-        int i = 0;
-        if (lane == 0) i = atomicAdd(&w.cnt->sampler_head, 1);
-        i = __shfl(i, 0, 64);
-        if (i >= n_list) break;
-        const int ray = w.sampler_list[i];
-        const float ox = a.ray_o[3 * (size_t)ray], oy = a.ray_o[3 * (size_t)ray + 1], oz = a.ray_o[3 * (size_t)ray + 2];
-        const float dx = a.ray_d[3 * (size_t)ray], dy = a.ray_d[3 * (size_t)ray + 1], dz = a.ray_d[3 * (size_t)ray + 2];
-        const float t = a.dist[ray], s0 = a.sdf[ray];
-        // raytracer.py:59-65: sample [t, far] if sdf > 0 else [near, t]
-        const bool pos = s0 > 0.0f;
-        const float smin = pos ? t : a.near[ray];
-        const float smax = pos ? a.far[ray] : t;
-        const float width = smax - smin;
-
-        bool root = false, done = false;
-        float z_lo = 0.f, f_lo = 0.f, z_hi = 0.f, f_hi = 0.f;
-        float prev_z = 0.f, prev_f = 0.f;
-        for (int blk = 0; blk * 32 < a.n_steps && !done; ++blk) {
-            const int idx = blk * 32 + j;
-            const bool in_range = idx < a.n_steps;
-            const float z = smin + a.lin[in_range ? idx : a.n_steps - 1] * width;  // raytracer.py:147-149
-            const float qx = ox + dx * z, qy = oy + dy * z, qz = oz + dz * z;       // raytracer.py:150
-            const float f = sdf_eval<kFastActT>(net, ws, qx, qy, qz, lane);
+        if (!has_ray && !exhausted) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&w.cnt->sampler_head, 1);
+            i = __shfl(i, 0, 64);
+            if (i >= n_list) {
+                exhausted = true;
+            } else {
+                ray = w.sampler_list[i];
+                ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
+                dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+                const float t = a.dist[ray], s0 = a.sdf[ray];
+                const bool pos = s0 > 0.0f;  // raytracer.py:59-65: sample [t, far] if sdf > 0 else [near, t]
+                smin = pos ? t : a.near[ray];
+                const float smax = pos ? a.far[ray] : t;
+                width = smax - smin;
+                blk = 0;
+                prev_z = prev_f = 0.f;
+                has_ray = true;
+            }
+        }
+        if (!be.any(has_ray)) break;
+        const int idx = blk * 32 + j;
+        const bool in_range = has_ray && idx < a.n_steps;
+        const float z = smin + a.lin[in_range ? idx : a.n_steps - 1] * width;                      // raytracer.py:147-149
+        const float qx = has_ray ? ox + dx * z : 0.f, qy = has_ray ? oy + dy * z : 0.f, qz = has_ray ? oz + dz * z : 0.f;  // :150
+        const float f = be.eval(qx, qy, qz);
+        if (has_ray) {
             const int n_in = a.n_steps - blk * 32;
             evals += n_in < 32 ? n_in : 32;
+            bool done = false, root = false;
+            float z_lo = 0.f, f_lo = 0.f, z_hi = 0.f, f_hi = 0.f;
             const unsigned neg = (unsigned)__ballot(in_range && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
             if (neg) {
                 const int first = __ffs(neg) - 1;
@@ -208,21 +275,27 @@ __global__ __launch_bounds__(64, 1) void k_sampler(SdfNetDev net, TraceArgs a, T
             }
             prev_z = __shfl(z, 31, 64);
             prev_f = __shfl(f, 31, 64);
-        }
-        if (lane == 0) {
-            if (root) {
-                const int pos_l = atomicAdd(&w.cnt->n_root, 1);
-                w.root_list[pos_l] = ray;
-                w.root_lo[pos_l] = z_lo; w.root_hi[pos_l] = z_hi;
-                w.root_flo[pos_l] = f_lo; w.root_fhi[pos_l] = f_hi;
-            } else {  // raytracer.py:158-160, 75-78: sampled rays without a root get zeros
-                a.conv[ray] = 0;
-                a.points[3 * (size_t)ray] = 0.f; a.points[3 * (size_t)ray + 1] = 0.f; a.points[3 * (size_t)ray + 2] = 0.f;
-                a.sdf[ray] = 0.f;
-                a.dist[ray] = 0.f;
+            ++blk;
+            if (blk * 32 >= a.n_steps) done = true;
+            if (done) {
+                if (lane == 0) {
+                    if (root) {
+                        const int pos_l = atomicAdd(&w.cnt->n_root, 1);
+                        w.root_list[pos_l] = ray;
+                        w.root_lo[pos_l] = z_lo; w.root_hi[pos_l] = z_hi;
+                        w.root_flo[pos_l] = f_lo; w.root_fhi[pos_l] = f_hi;
+                    } else {  // raytracer.py:158-160, 75-78: sampled rays without a root get zeros
+                        a.conv[ray] = 0;
+                        a.points[3 * (size_t)ray] = 0.f; a.points[3 * (size_t)ray + 1] = 0.f; a.points[3 * (size_t)ray + 2] = 0.f;
+                        a.sdf[ray] = 0.f;
+                        a.dist[ray] = 0.f;
+                    }
+                }
+                has_ray = false;
             }
         }
     }
+    be.finish();
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
 }
 
@@ -232,43 +305,19 @@ __device__ __forceinline__ long long ray_chunk(const TraceArgs& a, int ray) {
 }
 
 // rootfind, per-ray part (raytracer.py:199-217)
-__global__ __launch_bounds__(64, 1) void k_bisect_a(SdfNetDev net, TraceArgs a, TraceWs w) {
-    const int lane = threadIdx.x;
+template <class BE>
+__global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_a(IRON_TRACE_KERNEL_ARGS) {
+    BE be;
+    be.init(net, hs, hm);
+    const int lane = be.lane;
     const int j = lane & 31;
-    WStream ws;
-    ws.init(net.blob, net.blob_bytes, lane);
     const int n_root = w.cnt->n_root;
     const float thr2 = 2.0f * a.thr;
     long long evals = 0;
-    for (;;) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&w.cnt->root_head_a, 32);
-        base = __shfl(base, 0, 64);
-        if (base >= n_root) break;
-        const int li = base + j;
-        const bool valid = li < n_root;
-        const int ray = valid ? w.root_list[li] : 0;
-        float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f;
-        bool work = false;
-        if (valid) {
-            ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
-            dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
-            lo = w.root_lo[li]; hi = w.root_hi[li];
-            work = (w.root_flo[li] > 0.0f) && (w.root_fhi[li] < 0.0f);
-        }
-        float mid = (lo + hi) / 2.0f;
-        int k = 0;
-        unsigned wm;
-        while ((wm = (unsigned)__ballot(work)) != 0u) {
-            evals += __popc(wm);
-            const float f = sdf_eval<kFastActT>(net, ws, ox + dx * mid, oy + dy * mid, oz + dz * mid, lane);
-            if (work) {
-                if (f > 0.0f) lo = mid; else hi = mid;
-                mid = (lo + hi) / 2.0f;
-                ++k;
-                work = ((hi - lo) > thr2) && (k < 64);  // k < 64: exit bound for non-finite intervals
-            }
-        }
+    bool has_batch = false, exhausted = false, valid = false, work = false;
+    int li = 0, ray = 0, k = 0;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f, mid = 0.f;
+    auto store = [&]() {
         if (valid && lane < 32) {
             w.root_lo[li] = lo; w.root_hi[li] = hi;
             w.root_k[li] = k;
@@ -276,59 +325,112 @@ __global__ __launch_bounds__(64, 1) void k_bisect_a(SdfNetDev net, TraceArgs a, 
             atomicAdd(&w.chunk_roots[ch], 1);
             if (k > 0) atomicMax(&w.chunk_iters[ch], k);
         }
+    };
+    for (;;) {
+        while (!has_batch && !exhausted) {  // wave-local: batches that need no evaluation are finished here
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&w.cnt->root_head_a, 32);
+            base = __shfl(base, 0, 64);
+            if (base >= n_root) { exhausted = true; break; }
+            li = base + j;
+            valid = li < n_root;
+            ray = valid ? w.root_list[li] : 0;
+            ox = oy = oz = dx = dy = dz = lo = hi = 0.f;
+            work = false;
+            if (valid) {
+                ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
+                dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+                lo = w.root_lo[li]; hi = w.root_hi[li];
+                work = (w.root_flo[li] > 0.0f) && (w.root_fhi[li] < 0.0f);
+            }
+            mid = (lo + hi) / 2.0f;
+            k = 0;
+            if (__ballot(work) != 0ull) has_batch = true;
+            else store();
+        }
+        if (!be.any(has_batch)) break;
+        evals += has_batch ? __popc((unsigned)__ballot(work)) : 0;
+        const float f = be.eval(ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        if (has_batch) {
+            if (work) {
+                if (f > 0.0f) lo = mid; else hi = mid;
+                mid = (lo + hi) / 2.0f;
+                ++k;
+                work = ((hi - lo) > thr2) && (k < 64);  // k < 64: exit bound for non-finite intervals
+            }
+            if (__ballot(work) == 0ull) {
+                store();
+                has_batch = false;
+                ox = oy = oz = dx = dy = dz = mid = 0.f;
+            }
+        }
     }
+    be.finish();
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
 }
 
 // rootfind, chunk-global remainder + final evaluation (raytracer.py:204-219)
-__global__ __launch_bounds__(64, 1) void k_bisect_b(SdfNetDev net, TraceArgs a, TraceWs w) {
-    const int lane = threadIdx.x;
+template <class BE>
+__global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_b(IRON_TRACE_KERNEL_ARGS) {
+    BE be;
+    be.init(net, hs, hm);
+    const int lane = be.lane;
     const int j = lane & 31;
-    WStream ws;
-    ws.init(net.blob, net.blob_bytes, lane);
     const int n_root = w.cnt->n_root;
     long long evals = 0;
+    bool has_batch = false, exhausted = false, valid = false;
+    int li = 0, ray = 0, remaining = 0;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f, mid = 0.f;
     for (;;) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&w.cnt->root_head_b, 32);
-        base = __shfl(base, 0, 64);
-        if (base >= n_root) break;
-        const int li = base + j;
-        const bool valid = li < n_root;
-        const int ray = valid ? w.root_list[li] : 0;
-        float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, lo = 0.f, hi = 0.f;
-        int remaining = 0;
-        if (valid) {
-            ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
-            dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
-            lo = w.root_lo[li]; hi = w.root_hi[li];
-            remaining = w.chunk_iters[ray_chunk(a, ray)] - w.root_k[li];
-        }
-        float mid = (lo + hi) / 2.0f;
-        unsigned wm;
-        while ((wm = (unsigned)__ballot(remaining > 0)) != 0u) {
-            evals += __popc(wm);
-            const float f = sdf_eval<kFastActT>(net, ws, ox + dx * mid, oy + dy * mid, oz + dz * mid, lane);
-            if (remaining > 0) {
-                if (f > 0.0f) lo = mid; else hi = mid;
+        if (!has_batch && !exhausted) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&w.cnt->root_head_b, 32);
+            base = __shfl(base, 0, 64);
+            if (base >= n_root) {
+                exhausted = true;
+            } else {
+                li = base + j;
+                valid = li < n_root;
+                ray = valid ? w.root_list[li] : 0;
+                ox = oy = oz = dx = dy = dz = lo = hi = 0.f;
+                remaining = 0;
+                if (valid) {
+                    ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
+                    dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
+                    lo = w.root_lo[li]; hi = w.root_hi[li];
+                    remaining = w.chunk_iters[ray_chunk(a, ray)] - w.root_k[li];
+                }
                 mid = (lo + hi) / 2.0f;
-                --remaining;
+                has_batch = true;
             }
         }
+        if (!be.any(has_batch)) break;
+        const unsigned rem = has_batch ? (unsigned)__ballot(remaining > 0) : 0u;
         const float qx = ox + dx * mid, qy = oy + dy * mid, qz = oz + dz * mid;
-        const float f = sdf_eval<kFastActT>(net, ws, qx, qy, qz, lane);
-        const unsigned vm = (unsigned)__ballot(valid);
-        evals += __popc(vm);
-        if (valid && lane < 32) {  // raytracer.py:75-78: the sampler's mask overwrites convergent
-            a.conv[ray] = 1;
-            a.points[3 * (size_t)ray] = qx; a.points[3 * (size_t)ray + 1] = qy; a.points[3 * (size_t)ray + 2] = qz;
-            a.sdf[ray] = f;
-            a.dist[ray] = mid;
+        const float f = be.eval(qx, qy, qz);
+        if (has_batch) {
+            if (rem) {
+                evals += __popc(rem);
+                if (remaining > 0) {
+                    if (f > 0.0f) lo = mid; else hi = mid;
+                    mid = (lo + hi) / 2.0f;
+                    --remaining;
+                }
+            } else {  // this was the final mid-point evaluation (raytracer.py:218-219)
+                evals += __popc((unsigned)__ballot(valid));
+                if (valid && lane < 32) {  // raytracer.py:75-78: the sampler's mask overwrites convergent
+                    a.conv[ray] = 1;
+                    a.points[3 * (size_t)ray] = qx; a.points[3 * (size_t)ray + 1] = qy; a.points[3 * (size_t)ray + 2] = qz;
+                    a.sdf[ray] = f;
+                    a.dist[ray] = mid;
+                }
+                has_batch = false;
+                ox = oy = oz = dx = dy = dz = mid = 0.f;
+            }
         }
     }
-    if (lane == 0) {
-        atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
-    }
+    be.finish();
+    if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
 }
 
 __global__ void k_trace_stats(TraceWs w, int n_steps, iron_trace_stats* out) {
@@ -373,6 +475,10 @@ static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
     return L;
 }
 
+// which: 0 sphere, 1 sampler, 2 bisect_a, 3 bisect_b; `units` = wave-sized work items available
+static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const TraceArgs& a, const TraceWs& w, int64_t units,
+                                hipStream_t st);
+
 static int resident_waves() {
     // single-wave workgroups, one wave per SIMD (the kernels need > 256 registers per lane)
     static int cached = 0;
@@ -382,6 +488,41 @@ static int resident_waves() {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
     cached = prop.multiProcessorCount * 4;
     return cached;
+}
+
+static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const TraceArgs& a, const TraceWs& w, int64_t units,
+                                hipStream_t st) {
+    H2Meta m;
+    m.n_hidden_layers = sdf->sdf.n_hidden_layers; m.skip_layer = sdf->sdf.skip_layer; m.scale = sdf->sdf.scale; m.b_last = sdf->sdf.b_last;
+    if (units < 1) units = 1;
+    if (h2) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_sphere<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_sampler<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_bisect_a<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_bisect_b<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            attr = true;
+        }
+        const int64_t wgs = (units + 3) / 4;
+        const int cus = resident_waves() / 4;
+        const dim3 grid((unsigned)(wgs < cus ? wgs : cus)), block(256);
+        switch (which) {
+            case 0: hipLaunchKernelGGL(k_sphere<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 1: hipLaunchKernelGGL(k_sampler<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 2: hipLaunchKernelGGL(k_bisect_a<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            default: hipLaunchKernelGGL(k_bisect_b<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+        }
+    } else {
+        const int waves = resident_waves();
+        const dim3 grid((unsigned)(units < waves ? units : waves)), block(64);
+        switch (which) {
+            case 0: hipLaunchKernelGGL(k_sphere<BackendF32>, grid, block, 0, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 1: hipLaunchKernelGGL(k_sampler<BackendF32>, grid, block, 0, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 2: hipLaunchKernelGGL(k_bisect_a<BackendF32>, grid, block, 0, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            default: hipLaunchKernelGGL(k_bisect_b<BackendF32>, grid, block, 0, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+        }
+    }
 }
 
 }  // namespace iron
@@ -433,7 +574,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     a.lin = lin_steps; a.conv = conv; a.points = points; a.sdf = sdf_out; a.dist = dist;
     a.n = (int)n; a.n_steps = p->n_steps; a.iters = p->sphere_tracing_iters; a.thr = p->sdf_threshold;
     a.chunk = p->chunk > 0 ? p->chunk : 0;
-    const int waves = resident_waves();
+    const bool h2 = use_h2_core() && sdf->h2_blob && sdf->sdf.n_hidden_layers == 8 && sdf->sdf.skip_layer == 4;
     if (phase == 0) {
         IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, align256(sizeof(TraceCounters)), st));
         if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));
@@ -442,21 +583,21 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         const int64_t tiles = (n + 31) / 32;
         {
             ProfScope ps(IRON_PROF_SPHERE, st);
-            hipLaunchKernelGGL(k_sphere, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+            launch_trace_kernel(0, h2, sdf, a, w, tiles, st);
         }
         {
             ProfScope ps(IRON_PROF_SAMPLER, st);
-            hipLaunchKernelGGL(k_sampler, dim3((unsigned)(n < waves ? n : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+            launch_trace_kernel(1, h2, sdf, a, w, n, st);
         }
         {
             ProfScope ps(IRON_PROF_BISECT_A, st);
-            hipLaunchKernelGGL(k_bisect_a, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+            launch_trace_kernel(2, h2, sdf, a, w, tiles, st);
         }
     } else {
         const int64_t tiles = (n + 31) / 32;
         {
             ProfScope ps(IRON_PROF_BISECT_B, st);
-            hipLaunchKernelGGL(k_bisect_b, dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, st, sdf->sdf, a, w);
+            launch_trace_kernel(3, h2, sdf, a, w, tiles, st);
         }
         if (stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w, p->n_steps, stats);
     }

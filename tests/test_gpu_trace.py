@@ -72,14 +72,12 @@ def test_non_convergent_state_like_reference():
     zero_hip = same_nc & (d == 0.0) & (np.abs(res["points"].cpu().numpy()).sum(-1) == 0.0)
     # the zeroed (sampled, rootless) sets agree up to the few rays whose sphere-trace exit differs
     assert int((zero_ref != zero_hip).sum()) <= max(2, conv.size // 500)
+    # rays that left the unit sphere without converging keep their last sphere-tracing state (not zeros): the
+    # state agrees with the reference to the accumulated step error of <= 16 evaluations
     agree = same_nc & ~zero_ref & ~zero_hip
-    # rays that miss the unit sphere get exactly one evaluation at the closest-approach point -> tight agreement
-    cam = R.CameraSpec(int(g["W"]), int(g["H"]), t(g["K"]), t(g["W2C"]))
-    o, dvec, _ = cam.get_rays(cam.get_uv())
-    hit, _, _ = R.intersect_sphere(o.reshape(-1, 3), dvec.reshape(-1, 3), 1.0)
-    miss = agree & ~hit.reshape(conv.shape).numpy()
-    assert miss.sum() > 100
-    np.testing.assert_allclose(res["sdf"].cpu().numpy()[miss], g["sdf"][miss], rtol=0, atol=5e-6)
+    assert agree.sum() > 100
+    assert np.abs(res["distance"].cpu().numpy() - g["distance"])[agree].max() <= 5e-4
+    # (rays that miss the unit sphere altogether: tests/test_gpu_fullsize.py::test_tracer_edge_cases)
 
 
 def test_chunk_semantics_and_direct_forward():
