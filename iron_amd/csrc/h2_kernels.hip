@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_values_h2(H2StreamDev s, H2Meta 
 bool use_h2_core() {
     static int v = -1;
     if (v < 0) {
+        // default: the split-fp16 "h2" core; IRON_MLP_CORE=f32 selects the exact-fp32 MFMA core (mlp_core.h)
         const char* e = getenv("IRON_MLP_CORE");
-        v = (e && e[0] == 'h') ? 1 : 0;
+        v = (e && e[0] == 'f') ? 0 : 1;
     }
     return v == 1;
 }

@@ -50,15 +50,18 @@ __device__ __forceinline__ f32x16 mfma_h(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// fp32 pair -> packed (hi, scaled lo) fp16 pairs, as raw dwords
+// fp32 pair -> packed (hi, scaled lo) fp16 pairs, as raw dwords.  Both conversions round to nearest
+// (v_cvt_pk_f16_f32 on gfx950); x - hi is exact in fp32, so the pair carries 22 mantissa bits.
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const float r0 = (x0 - (float)h[0]) * kLoScale;
-    const float r1 = (x1 - (float)h[1]) * kLoScale;
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    f16x2 h;
+    h[0] = (_Float16)x0;
+    h[1] = (_Float16)x1;
+    f16x2 l;
+    l[0] = (_Float16)((x0 - (float)h[0]) * kLoScale);
+    l[1] = (_Float16)((x1 - (float)h[1]) * kLoScale);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }

@@ -21,5 +21,5 @@ for scene in ("S0", "S1"):
         a = a.double(); b = b.double()
         return "max|d| %.3e  relL2 %.3e" % ((a - b).abs().max().item(), ((a - b).norm() / b.norm()).item())
     print(scene, "sdf   hip~ref32:", stats(out[:, 0], ref[:, 0]), "| hip~ref64:", stats(out[:, 0], ref64[:, 0]), "| ref32~ref64:", stats(ref[:, 0], ref64[:, 0]))
-    print(scene, ".sdf() hip~ref32:", stats(only, ref[:, 0]), "| hip~ref64:", stats(only, ref64[:, 0]), "  (core:", os.environ.get("IRON_MLP_CORE", "f32"), ")")
+    print(scene, ".sdf() hip~ref32:", stats(only, ref[:, 0]), "| hip~ref64:", stats(only, ref64[:, 0]), "  (core:", os.environ.get("IRON_MLP_CORE", "h2 (default)"), ")")
     print(scene, "feat  hip~ref32:", stats(out[:, 1:], ref[:, 1:]), "| hip~ref64:", stats(out[:, 1:], ref64[:, 1:]), "| ref32~ref64:", stats(ref[:, 1:], ref64[:, 1:]))
