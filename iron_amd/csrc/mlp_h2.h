@@ -152,7 +152,9 @@ struct Ring {
     }
     __device__ __forceinline__ void sync() {
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#ifndef IRON_H2_NO_BARRIER  // timing experiment only
         __builtin_amdgcn_s_barrier();
+#endif
     }
     // before the kernel ends: no DMA may still be writing this workgroup's LDS
     __device__ __forceinline__ void drain() {
@@ -229,8 +231,8 @@ __device__ __forceinline__ f32x16 h2_combine(const f32x16& hi, const f32x16& lo)
 // k-step ahead of the MFMAs that consume them, and the VALU epilogue of the PREVIOUS output tile (combine,
 // softplus, fp16 split: ~15 VALU per k-step) is spread between the MFMAs, which execute asynchronously.
 // mask values (LLVM SchedGroupMask): VALU 0x2, MFMA 0x8, DS_READ 0x100.
-#ifndef IRON_H2_STEP_MASK
-#define IRON_H2_STEP_MASK 0x4  // only SALU may cross a k-step boundary: keeps each step's reads / MFMAs / VALU slice together
+#ifndef IRON_H2_VALU_PER_MFMA
+#define IRON_H2_VALU_PER_MFMA 5
 #endif
 
 // One ring step on a head slot: fragments [k-step 0..2][piece hi, lo] (+ padding)
@@ -248,6 +250,13 @@ __device__ __forceinline__ void step_head(const char* __restrict__ rd, const cha
         acc_lo = mfma_h(wl, hd.h[ks], acc_lo);
     }
 }
+
+// Empty asm statements that take values as read-write operands: they are chained to the side-effect order (barriers,
+// sched_barrier), so the producing instructions cannot float away from the place in the stream they were written at.
+__device__ __forceinline__ void pin8(float* a) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+__device__ __forceinline__ void pin16(float* a) { pin8(a); pin8(a + 8); }
 
 // epilogue of one output tile: z = hi + lo * 2^-11, activation, split into next-layer B fragments
 template <bool FAST>
@@ -269,8 +278,16 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     dma_issue(src, wr, src_hidden, wave);
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
     half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
-    float act[16];   // activated pending tile, produced one element per k-step
+    // The previous tile's epilogue runs as a 16-stage software pipeline, one stage per k-step, each stage applied
+    // to all 16 elements of the tile: a stage is 8..16 INDEPENDENT VALU ops (~70-90 issue cycles) placed behind the
+    // k-step's three MFMAs (96 cycles in the matrix pipe), and it consumes what the previous stage produced a whole
+    // k-step earlier, so no dependent VALU chain ever stalls the in-order wave.  sched_barrier(0) keeps hipcc from
+    // re-clustering (left alone it issues the 48 MFMAs first and the ~250 VALU ops afterwards, pipe idle).
+    float z[16], e[16], hb[16], rr[16];
+    f16x2 hp[8];
     u32x4 oh[2], ol[2];
+    constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
+    constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         half8 nh = fh, nl = fl;
@@ -284,34 +301,52 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
         fh = nh;
         fl = nl;
-        // VALU slice of the previous tile's epilogue, placed in program order behind this k-step's MFMAs (they
-        // execute asynchronously): element ks -> combine + softplus; every second k-step one fp16 pair is split.
         if constexpr (EPI != 0) {
-            act[ks] = softplus100<FAST>(fmaf(p_lo[ks], kLoInv, p_hi[ks]));
+            static_assert(FAST, "the staged epilogue implements the v_exp/v_log softplus");
+            if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin16(z); }
+            if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = z[i] * kC1; pin16(e); }
+            if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
+            if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
+            if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
+            if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
+            if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
+            if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = e[i] * kC2; pin16(e); }
+            if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = z[i] > 0.2f ? z[i] : e[i]; pin16(z); }  // 100 z > 20
             if constexpr (EPI == 1) {
-                if (ks & 1) {
-                    unsigned a, b2;
-                    split2(act[ks - 1], act[ks], a, b2);
-                    oh[ks >> 3][(ks >> 1) & 3] = a;
-                    ol[ks >> 3][(ks >> 1) & 3] = b2;
+                if (ks == 9) {
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { hp[i][0] = (_Float16)z[2 * i]; hp[i][1] = (_Float16)z[2 * i + 1]; }
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { hb[2 * i] = (float)hp[i][0]; hb[2 * i + 1] = (float)hp[i][1]; }
+                    pin16(hb);
+                }
+                if (ks == 10) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = z[i] - hb[i]; pin16(rr); }
+                if (ks == 11) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = rr[i] * kLoScale; pin16(rr); }
+                if (ks == 12) {
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+                        f16x2 lp;
+                        lp[0] = (_Float16)rr[2 * i];
+                        lp[1] = (_Float16)rr[2 * i + 1];
+                        oh[i >> 2][i & 3] = __builtin_bit_cast(unsigned, hp[i]);
+                        ol[i >> 2][i & 3] = __builtin_bit_cast(unsigned, lp);
+                    }
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(IRON_H2_STEP_MASK);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (EPI == 1) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            // pin to this step (LLVM would otherwise sink the epilogue to the end of the layer) and park the finished
+            // fragments in the AGPR file
+            asm volatile("" : "+a"(oh[s2]), "+a"(ol[s2]));
             out_prev.h[s2] = __builtin_bit_cast(half8, oh[s2]);
             out_prev.l[s2] = __builtin_bit_cast(half8, ol[s2]);
-            // pin to this step (LLVM would otherwise sink the whole epilogue to the end of the layer)
-            asm volatile("" ::"v"(oh[s2]), "v"(ol[s2]));
         }
     }
     if constexpr (EPI == 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hf_prev[i] = act[i];
-        asm volatile("" ::"v"(hf_prev));
+        for (int i = 0; i < 16; ++i) hf_prev[i] = z[i];
+        asm volatile("" : "+v"(hf_prev));
     }
 }
 
