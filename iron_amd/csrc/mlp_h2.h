@@ -141,7 +141,7 @@ struct Ring {
     __device__ __forceinline__ RingStep step() {
         RingStep s;
         s.hidden = kind_of(q_issue);
-        s.src = gbase + off_issue + lane * 16;
+        s.src = gbase + off_issue + (s.hidden ? lane * 16 : lane * 4);
         s.wr = lds + kLdsRing + b_issue * kSlotBytes;
         s.rd = lds + kLdsRing + b_take * kSlotBytes;
         off_issue += s.hidden ? (uint32_t)kSlotBytes : 8192u;
@@ -163,25 +163,8 @@ struct Ring {
     }
 };
 
-// One of this wave's 8 LDS-DMA instructions of a slot (i = 0..7).  Every slot is refilled as 32 pieces of 1 KiB,
-// also the 8 KiB head slots (the extra 24 KiB are the following slots' bytes, never read): one instruction form, no
-// branch, so the issues can be spread over the k-steps of the consuming tile and overlap its MFMAs.
-__device__ __forceinline__ void dma_issue_one(const char* src, char* __restrict__ wr, int wave, int i) {
-#ifdef IRON_H2_NO_DMA  // timing experiment only: results are garbage
-    return;
-#endif
-    const int f = wave + 4 * i;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
-                                     (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
-}
-
-// this wave's 8 LDS-DMA instructions of one slot, all at once (ring start, head slots)
+// this wave's 8 LDS-DMA instructions of one slot
 __device__ __forceinline__ void dma_issue(const char* src, char* __restrict__ wr, bool hidden, int wave) {
-#pragma unroll
-    for (int i = 0; i < kLoadsPerSlot; ++i) dma_issue_one(src, wr, wave, i);
-}
-
-__device__ __forceinline__ void dma_issue_unused(const char* src, char* __restrict__ wr, bool hidden, int wave) {
 #ifdef IRON_H2_NO_DMA  // timing experiment only: results are garbage
     return;
 #endif
@@ -292,6 +275,7 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
                                             const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
                                             const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
                                             const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev) {
+    dma_issue(src, wr, src_hidden, wave);
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
     half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
     // The previous tile's epilogue runs as a 16-stage software pipeline, one stage per k-step, each stage applied
@@ -317,7 +301,6 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
         fh = nh;
         fl = nl;
-        if ((ks & 1) == 0) dma_issue_one(src, wr, wave, ks >> 1);  // refill of the freed ring buffer, under the MFMAs
         if constexpr (EPI != 0) {
             static_assert(FAST, "the staged epilogue implements the v_exp/v_log softplus");
             if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin16(z); }
