@@ -31,6 +31,9 @@ FLOP_SDF_GRAD = 2 * (524544 + 459008)   # per hit: full forward (257 outs) + inp
 FLOP_MATERIALS = 2 * 818176             # per hit: the three material MLPs
 FLOP_PER_HIT = FLOP_SDF_GRAD + FLOP_MATERIALS
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA = 2.5e15          # dense f16/bf16 MFMA (the pipe the default "h2" core executes on)
+MFMA_FLOP_PER_EVAL_H2 = 3 * 2 * (7 * 256 * 256 + 2 * 8 * 3 * 16 * 32)   # executed: 3 f16 products per MAC, padded shapes
+MFMA_FLOP_PER_EVAL_F32 = 7488 * 4096 // 32
 
 
 def parse():
@@ -192,8 +195,17 @@ def main():
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get(dom, {}).get("bytes_per_launch")
+            core = os.environ.get("IRON_MLP_CORE", "h2")
+            exec_evals = {"sphere": E_sphere, "sampler": E_hip - E_sphere - n_bisect * 9}.get(dom)
+            executed = None
+            if exec_evals is not None and dom in ("sphere", "sampler"):
+                per = MFMA_FLOP_PER_EVAL_H2 if core.startswith("h") else MFMA_FLOP_PER_EVAL_F32
+                pk = PEAK_F16_MFMA if core.startswith("h") else PEAK_FP32_MFMA
+                ex = per * exec_evals / world / avg_s
+                executed = {"mfma_tflops": ex / 1e12, "pipe": "f16 (fp32 = 2 x fp16 split, 3 products)" if core.startswith("h") else "f32",
+                            "pipe_peak": pk / 1e12, "frac_of_pipe_peak": ex / pk}
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
+                    "frac": ach / PEAK_FP32_MFMA, "traffic": traffic, "core": core, "executed": executed,
                     "algorithmic_flop_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["ms_avg"],
                     "note": "algorithmic FLOP = 918016 x the evaluations the REFERENCE makes for this kernel's rays "
                             "(the sampler stops at the first negative block, so it executes fewer)"}
@@ -201,6 +213,7 @@ def main():
             "metric": "Mrays/s sphere-trace+GGX shade, drv/dragon 800x800 (synthetic S0)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mlp_core": os.environ.get("IRON_MLP_CORE", "h2") + (" (fp32-accurate split-fp16 MFMA, LDS weight ring)" if not os.environ.get("IRON_MLP_CORE", "h2").startswith("f") else " (exact fp32 MFMA)"),
             "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
                                    "sphere-trace + GGX shade, fp32" % (a.scene, a.res, a.res),
                        "views_per_step": n_views, "rays_per_step": rays,
