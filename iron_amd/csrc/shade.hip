@@ -10,7 +10,8 @@
 //                 layout so the material kernels reload them as B operands without a transpose.
 //   k_material    RenderingNetwork.forward (models/fields.py:203-239): one wave per 32 hits and net.
 //   k_ggx_shade   normalise, get_materials post-ops (models/rendering_func.py:5-16), GGX, scatter.
-#include "mlp_core.h"
+#include "mlp_h2.h"
+#include "h2_setup.h"
 #include "ggx_core.h"
 
 namespace iron {
@@ -173,6 +174,138 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad(SdfNetDev net, GradArgs a) 
         }
         __syncthreads();  // the next tile's layer 0 reuses sbuf[0]
     }
+}
+
+// ---- get_all on the h2 core ---------------------------------------------------------------------------
+// Same roles as k_sdf_grad (wave 0 = value, waves 1..3 = forward-mode tangents d/dx, d/dy, d/dz of the same
+// 32 points), but all four waves walk ONE weight stream through the LDS ring (mlp_h2.h) in lock step.  Per output
+// tile: MFMAs (value adds the bias) -> the value wave's epilogue writes sigma'(z) of the tile to a 4 KiB LDS
+// buffer -> barrier -> the tangent waves scale their tile by it.  The feature rows of the last layer are 8 more
+// ring slots that only the value wave multiplies.
+constexpr int kLdsSbuf = kLdsH2Total;               // [16 regs][64 lanes] f32 = 4 KiB
+constexpr int kLdsGradTotal = kLdsH2Total + 4096;
+
+__device__ __forceinline__ void lds_publish_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m, GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_value = wave == 0;
+    const int axis = wave - 1;
+    Ring ring;
+    h2_setup(hs, lds, ring);
+    float* sbuf = reinterpret_cast<float*>(lds + kLdsSbuf);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+    const bool want_feat = (a.feat_packed != nullptr) || (a.feat_rows != nullptr);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int src = ok ? (a.list ? a.list[li] : li) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (ok) { px = a.x[3 * (size_t)src]; py = a.x[3 * (size_t)src + 1]; pz = a.x[3 * (size_t)src + 2]; }
+        const float sx = px * m.scale, sy = py * m.scale, sz = pz * m.scale;
+
+        float head[kHeadSlots];
+#pragma unroll
+        for (int i = 0; i < kHeadSlots; ++i) head[i] = 0.0f;
+        if (is_value) head_fill<kSdfPeLevels>(sx, sy, sz, half, head);
+        else head_fill_tangent<kSdfPeLevels>(sx, sy, sz, axis, half, head);
+        HeadFrag hd;
+        split_head(head, hd);
+
+        TileFrag in[kHidTiles], out[kHidTiles];
+        f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
+        TileFrag dummy_out;
+        f32x16 dummy_hf;
+        for (int l = 0; l < m.n_hidden_layers; ++l) {
+            const bool last = (l == m.n_hidden_layers - 1);
+            const bool with_head = (l == 0) || (l == m.skip_layer);
+            const char* bias = lds + kLdsBias + l * 1024;
+            if (l > 0) {
+#pragma unroll
+                for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
+            }
+#define IRON_GTILE(TO)                                                                                                  \
+    {                                                                                                                   \
+        f32x16 a_hi = zero16(), a_lo = zero16();                                                                        \
+        if (with_head) {                                                                                                \
+            ring.sync();                                                                                                \
+            const RingStep sh = ring.step();                                                                            \
+            step_head(sh.rd, bias, sh.wr, sh.src, sh.hidden, wave, lane, TO, false, hd, a_hi, a_lo);                    \
+        }                                                                                                               \
+        if (l > 0) {                                                                                                    \
+            ring.sync();                                                                                                \
+            const RingStep st = ring.step();                                                                            \
+            step_hidden<kFastActS, 0>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, false, in, a_hi, a_lo,     \
+                                      a_hi, a_lo, dummy_out, dummy_hf);                                                 \
+        }                                                                                                               \
+        f32x16 zt = h2_combine(a_hi, a_lo);                                                                             \
+        if (is_value) {                                                                                                 \
+            const f32x16 bt = lds_half_tile(bias, TO, half);                                                            \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
+                float hv, sv;                                                                                           \
+                softplus100_both<kFastActS>(zt[r] + bt[r], hv, sv);                                                     \
+                zt[r] = hv;                                                                                             \
+                sbuf[r * 64 + lane] = sv;                                                                               \
+            }                                                                                                           \
+        }                                                                                                               \
+        lds_publish_barrier();                                                                                          \
+        if (!is_value) {                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) zt[r] *= sbuf[r * 64 + lane];                                \
+        }                                                                                                               \
+        if (last) hf[TO] = zt;                                                                                          \
+        else split_tile(zt, out[TO]);                                                                                   \
+    }
+            IRON_GTILE(0) IRON_GTILE(1) IRON_GTILE(2) IRON_GTILE(3) IRON_GTILE(4) IRON_GTILE(5) IRON_GTILE(6) IRON_GTILE(7)
+#undef IRON_GTILE
+        }
+
+        if (is_value) {
+            const float s = (row_dot_lds(lds + kLdsRows, hf, half) + m.b_last) / m.scale;
+            if (ok && lane < 32 && a.sdf_out) a.sdf_out[li] = s;
+        } else {
+            const float g = row_dot_lds(lds + kLdsRows, hf, half);
+            if (ok && lane < 32 && a.grad_out) a.grad_out[3 * (size_t)li + axis] = g;
+        }
+        // feature rows: 8 more ring slots (every wave steps the ring; only the value wave multiplies)
+        if (want_feat) {
+            if (is_value) {
+#pragma unroll
+                for (int t = 0; t < kHidTiles; ++t) split_tile(hf[t], in[t]);
+            }
+            const char* fb = lds + kLdsBias + m.n_hidden_layers * 1024;
+            float* dst = a.feat_packed ? a.feat_packed + (size_t)tile * kSBufFloats : nullptr;
+#define IRON_FTILE(TO)                                                                                                  \
+    {                                                                                                                   \
+        ring.sync();                                                                                                    \
+        const RingStep st = ring.step();                                                                                \
+        f32x16 a_hi = zero16(), a_lo = zero16();                                                                        \
+        if (is_value) {                                                                                                 \
+            step_hidden<kFastActS, 0>(st.rd, fb, st.wr, st.src, st.hidden, wave, lane, TO, true, in, a_hi, a_lo,        \
+                                      a_hi, a_lo, dummy_out, dummy_hf);                                                 \
+            const f32x16 o = h2_combine(a_hi, a_lo);                                                                    \
+            if (dst) { _Pragma("unroll") for (int r = 0; r < 16; ++r) dst[((TO) * 16 + r) * 64 + lane] = o[r]; }       \
+            if (a.feat_rows && ok) {                                                                                    \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                          \
+                    a.feat_rows[(size_t)li * kHidden + 32 * (TO) + (r & 3) + 8 * (r >> 2) + 4 * half] = o[r];           \
+            }                                                                                                           \
+        } else {                                                                                                        \
+            dma_issue(st.src, st.wr, st.hidden, wave);                                                                  \
+        }                                                                                                               \
+    }
+            IRON_FTILE(0) IRON_FTILE(1) IRON_FTILE(2) IRON_FTILE(3) IRON_FTILE(4) IRON_FTILE(5) IRON_FTILE(6) IRON_FTILE(7)
+#undef IRON_FTILE
+        }
+    }
+    ring.drain();
 }
 
 // ---- material networks ------------------------------------------------------------------------------
@@ -378,6 +511,24 @@ static int cu_count() {
 }
 
 static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st) {
+    if (use_h2_core() && sdf->h2_blob && sdf->sdf.n_hidden_layers == 8 && sdf->sdf.skip_layer == 4) {
+        static bool attr2 = false;
+        if (!attr2) {
+            IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_sdf_grad_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsGradTotal));
+            attr2 = true;
+        }
+        const bool want_feat = a.feat_packed || a.feat_rows;
+        if (want_feat && !sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
+        H2Meta m;
+        m.n_hidden_layers = sdf->sdf.n_hidden_layers; m.skip_layer = sdf->sdf.skip_layer; m.scale = sdf->sdf.scale; m.b_last = sdf->sdf.b_last;
+        const int cus = cu_count();
+        const unsigned grid = (unsigned)(max_tiles < cus ? (max_tiles > 0 ? max_tiles : 1) : cus);
+        ProfScope ps(IRON_PROF_SDF_GRAD, st);
+        // the stream must match what the kernel walks: with features the 80-slot sequence, else the 72-slot one
+        hipLaunchKernelGGL(k_sdf_grad_h2, dim3(grid), dim3(256), kLdsGradTotal, st, want_feat ? sdf->h2_full : sdf->h2_trace, m, a);
+        IRON_HIP_TRY(hipGetLastError());
+        return IRON_OK;
+    }
     const size_t lds_bytes = 2 * kSBufFloats * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
