@@ -270,7 +270,8 @@ __device__ __forceinline__ void h2_epilogue_split(const f32x16& hi, const f32x16
 // EPI: 0 = nothing pending, 1 = pending tile -> split fragments, 2 = pending tile -> f32 tile (last layer).
 // rd / bias / wr are distinct LDS regions (see the note above): __restrict__ is what lets the reads proceed
 // while the refill is in flight.
-template <bool FAST, int EPI>
+// ACT: 0 = softplus(beta=100) (SDF net), 1 = relu (material nets).
+template <bool FAST, int EPI, int ACT = 0>
 __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
                                             const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
                                             const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
@@ -304,14 +305,18 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         if constexpr (EPI != 0) {
             static_assert(FAST, "the staged epilogue implements the v_exp/v_log softplus");
             if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin16(z); }
-            if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = z[i] * kC1; pin16(e); }
-            if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
-            if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
-            if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
-            if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
-            if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
-            if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = e[i] * kC2; pin16(e); }
-            if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = z[i] > 0.2f ? z[i] : e[i]; pin16(z); }  // 100 z > 20
+            if constexpr (ACT == 0) {
+                if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = z[i] * kC1; pin16(e); }
+                if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
+                if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
+                if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
+                if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
+                if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
+                if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = e[i] * kC2; pin16(e); }
+                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = z[i] > 0.2f ? z[i] : e[i]; pin16(z); }  // 100 z > 20
+            } else {
+                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaxf(z[i], 0.0f); pin16(z); }
+            }
             if constexpr (EPI == 1) {
                 if (ks == 9) {
                     _Pragma("unroll") for (int i = 0; i < 8; ++i) { hp[i][0] = (_Float16)z[2 * i]; hp[i][1] = (_Float16)z[2 * i + 1]; }
@@ -352,7 +357,7 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
 
 // One 256 -> 256 layer on the ring.  HEAD: the layer also has a head product (skip layer); LAST: the result is
 // delivered as f32 tiles in `hf` instead of split fragments in `out`.
-template <bool FAST, bool HEAD, bool LAST>
+template <bool FAST, bool HEAD, bool LAST, int ACT = 0>
 __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, const HeadFrag& hd, int lane,
                                                 const TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
                                                 f32x16 (&hf)[kHidTiles]) {
@@ -373,20 +378,25 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
         ring.sync();                                                                                                       \
         const RingStep st = ring.step();                                                                                   \
         if constexpr ((TO) == 0)                                                                                           \
-            step_hidden<FAST, 0>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+            step_hidden<FAST, 0, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
                                  acc[Q][0], acc[Q][1], dummy_out, dummy_hf);                                               \
         else if constexpr (LAST)                                                                                           \
-            step_hidden<FAST, 2>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+            step_hidden<FAST, 2, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
                                  acc[Q][0], acc[Q][1], dummy_out, hf[(TO) > 0 ? (TO) - 1 : 0]);                            \
         else                                                                                                               \
-            step_hidden<FAST, 1>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
+            step_hidden<FAST, 1, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
                                  acc[Q][0], acc[Q][1], out[(TO) > 0 ? (TO) - 1 : 0], dummy_hf);                            \
     }
     IRON_H2_TILE(0) IRON_H2_TILE(1) IRON_H2_TILE(2) IRON_H2_TILE(3)
     IRON_H2_TILE(4) IRON_H2_TILE(5) IRON_H2_TILE(6) IRON_H2_TILE(7)
 #undef IRON_H2_TILE
-    if constexpr (LAST) hf[kHidTiles - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
-    else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[kHidTiles - 1]);
+    if constexpr (ACT == 0) {
+        if constexpr (LAST) hf[kHidTiles - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
+        else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[kHidTiles - 1]);
+    } else {
+        if constexpr (LAST) hf[kHidTiles - 1] = relu_tile(h2_combine(acc[1][0], acc[1][1]));
+        else split_tile(relu_tile(h2_combine(acc[1][0], acc[1][1])), out[kHidTiles - 1]);
+    }
 }
 
 // dot of this lane's 128 resident f32 features with a row held in LDS ([8][2][16] f32), summed over the halves

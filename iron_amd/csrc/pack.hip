@@ -345,7 +345,7 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     r.squeeze_out_scale = d.squeeze_out_scale;
     r.output_bias = d.output_bias;
     r.output_scale = d.output_scale;
-    return IRON_OK;
+    return build_h2_render(net, L, scale_base, soff, hs, head_w, st);
 }
 
 }  // namespace

@@ -137,4 +137,54 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     return IRON_OK;
 }
 
+// h2 stream of a material network.  Sequence: layer 0: per output tile [head slot][hidden slot = feature part];
+// layers 1..n-2: hidden slots.  Side blocks: biases of layers 0..n-2, rows 0..d_out-1 of the last layer.
+int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, const HeadSrcs& hs,
+                    int head_w, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int nl = d.n_linear;
+    std::vector<uint32_t> table;
+    size_t off = 0;
+    auto add = [&](int kind) { table.push_back((uint32_t)off); table.push_back((uint32_t)kind); off += kind ? kSlotBytes : 8192; };
+    for (int to = 0; to < kHidTiles; ++to) { add(0); add(1); }
+    for (int l = 1; l <= nl - 2; ++l)
+        for (int to = 0; to < kHidTiles; ++to) add(1);
+    const uint32_t n_slots = (uint32_t)(table.size() / 2);
+    if (n_slots > 127 || nl - 1 > 8) return IRON_ERR_UNSUPPORTED;
+    const size_t table_off = (off + 255) & ~(size_t)255;
+    const size_t bias_off = table_off + 1024;
+    const size_t rows_off = bias_off + kLdsBiasBytes;
+    const size_t total = rows_off + kLdsRowsBytes + 65536;
+    IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
+    IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
+    char* base = (char*)net->h2_blob;
+    size_t q = 0;
+    auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
+    for (int to = 0; to < kHidTiles; ++to) {
+        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to);
+        ++q;
+        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), to, head_w, kHidden);
+        ++q;
+    }
+    for (int l = 1; l <= nl - 2; ++l)
+        for (int to = 0; to < kHidTiles; ++to, ++q)
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), to, 0, kHidden);
+    for (int l = 0; l <= nl - 2; ++l)
+        hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, kHidden);
+    const iron_linear& last = L[nl - 1];
+    for (int o = 0; o < d.d_out; ++o)
+        hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)(base + rows_off + (size_t)o * 1024), make_pack_src(last, scale_base + soff[nl - 1], d.d_out, 0, 1.0f), o, 0, kHidden);
+    IRON_HIP_TRY(hipGetLastError());
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+    H2StreamDev s;
+    s.base = base; s.table_off = (uint32_t)table_off; s.n_slots = n_slots; s.bias_off = (uint32_t)bias_off;
+    s.rows_off = (uint32_t)rows_off; s.n_bias_layers = (uint32_t)(nl - 1);
+    for (int i = 0; i < 4; ++i) s.kind_mask[i] = 0;
+    for (size_t k = 0; k < table.size() / 2; ++k)
+        if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
+    net->h2_trace = s;
+    net->h2_full = s;
+    return IRON_OK;
+}
+
 }  // namespace iron

@@ -407,6 +407,88 @@ __global__ __launch_bounds__(64, 1) void k_material(RenderNetDev net, MatArgs a)
     }
 }
 
+// RenderingNetwork.forward on the h2 core: a workgroup = 4 waves = 4 tiles of 32 hits of the SAME network, sharing its
+// weight stream through the LDS ring.  Layer 0 = head product + feature product, relu layers, 1..3 output rows.
+template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
+__global__ __launch_bounds__(256, 1) void k_material_h2(H2StreamDev hs, RenderNetDev net, MatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Ring ring;
+    h2_setup(hs, lds, ring);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+    const int n_groups = (n_tiles + 3) / 4;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int tile = g * 4 + wave;
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int pi = ok ? (a.list ? a.list[li] : li) : 0;
+        const int ai = ok ? (a.list_order_aux ? li : pi) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 1.f, vx = 0.f, vy = 0.f, vz = 0.f;
+        if (ok) {
+            px = a.points[3 * (size_t)pi]; py = a.points[3 * (size_t)pi + 1]; pz = a.points[3 * (size_t)pi + 2];
+            if (a.normals) { nx = a.normals[3 * (size_t)ai]; ny = a.normals[3 * (size_t)ai + 1]; nz = a.normals[3 * (size_t)ai + 2]; }
+            if (a.normalise) {
+                const float nn = sqrtf((nx * nx + ny * ny) + nz * nz) + 1e-10f;
+                nx = nx / nn; ny = ny / nn; nz = nz / nn;
+            }
+            if (a.neg_normal_view) { vx = -nx; vy = -ny; vz = -nz; }
+            else if (a.view) { vx = a.view[3 * (size_t)ai]; vy = a.view[3 * (size_t)ai + 1]; vz = a.view[3 * (size_t)ai + 2]; }
+        }
+        float head[kHeadSlots];
+#pragma unroll
+        for (int i = 0; i < kHeadSlots; ++i) head[i] = 0.0f;
+        int base = 0;
+        head_fill<LP>(px, py, pz, half, head + base);
+        base += head_slots(LP);
+        if constexpr (HAS_VIEW) { head_fill<LV>(vx, vy, vz, half, head + base); base += head_slots(LV); }
+        if constexpr (HAS_NRM) { head_fill<0>(nx, ny, nz, half, head + base); base += 2; }
+        HeadFrag hd;
+        split_head(head, hd);
+
+        TileFrag in[kHidTiles], out[kHidTiles];
+        f32x16 hf[kHidTiles];
+        {   // features -> split fragments
+            const bool tile_ok = tile < n_tiles;
+            const float* src = (a.feat_packed && tile_ok) ? a.feat_packed + (size_t)tile * kSBufFloats : nullptr;
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                f32x16 v = zero16();
+                if (src) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = src[(t * 16 + r) * 64 + lane];
+                } else if (a.feat_rows && ok) {
+                    const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w4 = row[(32 * t + 8 * q + 4 * half) >> 2];
+                        v[4 * q] = w4.x; v[4 * q + 1] = w4.y; v[4 * q + 2] = w4.z; v[4 * q + 3] = w4.w;
+                    }
+                }
+                split_tile(v, out[t]);
+            }
+        }
+        for (int l = 0; l < net.n_hidden_layers; ++l) {
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
+            const char* bias = lds + kLdsBias + l * 1024;
+            if (l == net.n_hidden_layers - 1) h2_hidden_layer<true, false, true, 1>(ring, bias, hd, lane, in, out, hf);
+            else if (l == 0) h2_hidden_layer<true, true, false, 1>(ring, bias, hd, lane, in, out, hf);
+            else h2_hidden_layer<true, false, false, 1>(ring, bias, hd, lane, in, out, hf);
+        }
+        for (int c = 0; c < net.d_out; ++c) {
+            float v = row_dot_lds(lds + kLdsRows + c * 1024, hf, half) + net.b_last[c];
+            v = net.output_scale * (v + net.output_bias);  // fields.py:235
+            if (net.squeeze_out) v = net.squeeze_out_scale * (1.0f / (1.0f + expf(-v)));  // fields.py:236-237
+            if (ok && lane < 32) a.out[(size_t)li * net.d_out + c] = v;
+        }
+    }
+    ring.drain();
+}
+
 // ---- hit list + final pointwise stage ---------------------------------------------------------------
 __global__ void k_compact(const uint8_t* __restrict__ conv, int n, int* __restrict__ count, int* __restrict__ list) {
     const int stride = gridDim.x * blockDim.x;
@@ -552,6 +634,26 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
     const int lp = d.multires > 0 ? d.multires : 0;
     const int lv = d.multires_view > 0 ? d.multires_view : 0;
     ProfScope ps(IRON_PROF_MATERIAL, st);
+    if (use_h2_core() && net->h2_blob && r.n_hidden_layers >= 2) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)k_material_h2<0, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_material_h2<6, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            attr3 = true;
+        }
+        const int64_t groups = (max_tiles + 3) / 4;
+        const int cus = cu_count();
+        const unsigned g2 = (unsigned)(groups < cus ? (groups > 0 ? groups : 1) : cus);
+        if (d.mode == IRON_MODE_IDR && lp == 0 && lv == 4) {
+            hipLaunchKernelGGL((k_material_h2<0, 4, true, true>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a);
+        } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
+            hipLaunchKernelGGL((k_material_h2<6, 0, false, true>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a);
+        } else {
+            return IRON_ERR_UNSUPPORTED;
+        }
+        IRON_HIP_TRY(hipGetLastError());
+        return IRON_OK;
+    }
     if (d.mode == IRON_MODE_IDR && lp == 0 && lv == 4) {
         hipLaunchKernelGGL((k_material<0, 4, true, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
