@@ -124,6 +124,14 @@ int iron_ggx_colocated(float light, const float* distance, const float* normal, 
                        const float* tab_trans, const float* tab_diff_trans, int64_t n, float* diffuse_rgb,
                        float* specular_rgb, float* rgb, void* stream);
 
+/* Image-space passes of raytrace_camera's silhouette handling (models/raytracer.py:554-570), [H,W] fp32:
+ * iron_morph_closing3x3 = kornia.morphology.closing(depth, ones(3,3)) (erosion of the dilation, border never wins;
+ * `tmp` is an [H,W] scratch image); iron_sobel_magnitude = kornia.filters.sobel(depth) (kernels / 8, replicate
+ * border, sqrt(gx^2+gy^2+1e-6)).  kornia is not installable offline: both are restated from its documented
+ * semantics and are parity-unpinned. */
+int iron_morph_closing3x3(const float* depth, int32_t H, int32_t W, float* tmp, float* out, void* stream);
+int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sphere tracer.  Replaces RayTracer.forward = sphere_tracing + ray_sampler + rootfind
  * (models/raytracer.py:45-220) for a batch of n rays, with the per-call chunking of

@@ -67,6 +67,8 @@ SYMBOLS = {
     "iron_camera_rays": (C.c_int, [C.POINTER(_F), C.POINTER(_F), _P, _I64, _P, _P, _P, _P]),
     "iron_intersect_sphere": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
+    "iron_sobel_magnitude": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "iron_trace_workspace_bytes": (_SZ, [_I64, C.POINTER(iron_trace_params)]),
     "iron_trace": (C.c_int, [_P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                              _P, _SZ, _P]),

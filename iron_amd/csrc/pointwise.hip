@@ -70,6 +70,47 @@ __global__ void k_ggx(float light, const float* __restrict__ distance, const flo
     }
 }
 
+// 3x3 max (SIGN=+1) / min (SIGN=-1) filter with a border that never wins: the two passes of kornia's
+// morphology.closing(x, ones(3,3)) with its default 'geodesic' border (models/raytracer.py:554-557).
+template <int SIGN>
+__global__ void k_minmax3x3(const float* __restrict__ in, int H, int W, float* __restrict__ out) {
+    const int64_t n = (int64_t)H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        float v = in[i];
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const float u = in[(int64_t)yy * W + xx];
+                v = SIGN > 0 ? fmaxf(v, u) : fminf(v, u);
+            }
+        out[i] = v;
+    }
+}
+
+// kornia.filters.sobel(x) (normalized, eps = 1e-6; models/raytracer.py:569): Sobel kernels / 8, replicate border,
+// sqrt(gx^2 + gy^2 + 1e-6)
+__global__ void k_sobel(const float* __restrict__ in, int H, int W, float* __restrict__ out) {
+    const int64_t n = (int64_t)H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        float p[3][3];
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int yy = y + dy, xx = x + dx;
+                yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                p[dy + 1][dx + 1] = in[(int64_t)yy * W + xx];
+            }
+        const float gx = ((p[0][2] - p[0][0]) + 2.0f * (p[1][2] - p[1][0]) + (p[2][2] - p[2][0])) / 8.0f;
+        const float gy = ((p[2][0] - p[0][0]) + 2.0f * (p[2][1] - p[0][1]) + (p[2][2] - p[0][2])) / 8.0f;
+        out[i] = sqrtf(gx * gx + gy * gy + 1e-6f);
+    }
+}
+
 static inline int pw_grid(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -114,6 +155,27 @@ extern "C" int iron_ggx_colocated(float light, const float* distance, const floa
     hipLaunchKernelGGL(k_ggx, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, light, distance, normal, viewdir,
                        diffuse_albedo, specular_albedo, roughness, tab_trans, tab_diff_trans, n, diffuse_rgb,
                        specular_rgb, rgb);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_morph_closing3x3(const float* depth, int32_t H, int32_t W, float* tmp, float* out, void* stream) {
+    if (H < 0 || W < 0) return IRON_ERR_BAD_ARG;
+    const int64_t n = (int64_t)H * W;
+    if (n == 0) return IRON_OK;
+    if (!depth || !tmp || !out || tmp == out || tmp == depth) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_minmax3x3<1>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, depth, H, W, tmp);
+    hipLaunchKernelGGL(k_minmax3x3<-1>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, tmp, H, W, out);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, float* out, void* stream) {
+    if (H < 0 || W < 0) return IRON_ERR_BAD_ARG;
+    const int64_t n = (int64_t)H * W;
+    if (n == 0) return IRON_OK;
+    if (!depth || !out || depth == out) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_sobel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, depth, H, W, out);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

@@ -524,6 +524,164 @@ def render_camera(scene: Scene, cam: CameraSpec, prm: TracerParams = TracerParam
 
 
 # ----------------------------------------------------------------------------
+# silhouette handling -- models/raytracer.py:412-539, 554-585, 665-729
+# ----------------------------------------------------------------------------
+def morph_closing3x3(depth: Tensor) -> Tensor:
+    """kornia.morphology.closing(depth[None,None], ones(3,3)) as raytracer.py:554-557 calls it: erosion(dilation(x))
+    with kornia's default 'geodesic' border (the border never wins: -/+ 1e4 padding) => min-pool3(max-pool3(x)).
+    PARITY UNPINNED: kornia is not installed in the build container; restated from kornia's documented semantics."""
+    x = depth[None, None]
+    big = 1e4
+    d = F.max_pool2d(F.pad(x, (1, 1, 1, 1), value=-big), 3, stride=1)
+    e = -F.max_pool2d(F.pad(-d, (1, 1, 1, 1), value=-big), 3, stride=1)
+    return e[0, 0]
+
+
+def sobel_magnitude(depth: Tensor) -> Tensor:
+    """kornia.filters.sobel(depth[None,None]) (normalized=True, eps=1e-6) as raytracer.py:569 calls it: 3x3 Sobel
+    kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + 1e-6).  PARITY UNPINNED (see morph_closing3x3)."""
+    x = F.pad(depth[None, None], (1, 1, 1, 1), mode="replicate")
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+    gx = F.conv2d(x, kx[None, None])
+    gy = F.conv2d(x, kx.t().contiguous()[None, None])
+    return torch.sqrt(gx * gx + gy * gy + 1e-6)[0, 0]
+
+
+def unique_first(x: Tensor):
+    """raytracer.py:412-419: unique values and, for each, the index of its FIRST occurrence in x."""
+    uniq, inverse = torch.unique(x, return_inverse=True, dim=0)
+    perm = torch.arange(inverse.size(0), dtype=inverse.dtype)
+    inverse, perm = inverse.flip([0]), perm.flip([0])
+    return uniq, inverse.new_empty(uniq.size(0)).scatter_(0, inverse, perm)
+
+
+def project(cam: CameraSpec, points: Tensor) -> Tensor:
+    """raytracer.py:305-325."""
+    p = torch.cat([points, torch.ones_like(points[:, :1])], dim=1)
+    uv = torch.matmul(torch.matmul(p, cam.W2C.transpose(1, 0)), cam.K.transpose(1, 0))
+    return uv[:, :2] / uv[:, 2:3]
+
+
+@torch.no_grad()
+def locate_edge_points(scene: Scene, cam: CameraSpec, walk_start_points: Tensor, mask: Tensor, max_step: int = 16,
+                       step_size: float = 1e-3, dot_threshold: float = 5e-2, max_num_rays: int = 200000) -> Dict[str, Tensor]:
+    """raytracer.py:421-506: walk on the surface towards the silhouette (|n.v| <= dot_threshold)."""
+    finish = walk_start_points.clone()
+    found = mask.clone()
+    if mask.sum() > 0:
+        sh = list(walk_start_points.shape[:-1])
+        fin_parts, found_parts = [], []
+        cam_o = cam.C2W[:3, 3]
+        for cur in torch.split(walk_start_points[mask].clone().view(-1, 3), max_num_rays, dim=0):
+            f = torch.zeros_like(cur[..., 0]).bool()
+            nf = ~f
+            ray_o = cam_o.view(1, 3).expand(cur.shape[0], 3)
+            i = 0
+            while True:
+                view = ray_o[nf] - cur[nf]
+                view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+                sdf, _, nrm = sdf_get_all(scene.sdf_sd, scene.sdf_spec, cur[nf].view(-1, 3))
+                nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-10)
+                dot = (nrm * view).sum(dim=-1)
+                tmp_nf = dot.abs() > dot_threshold
+                f[nf] = ~tmp_nf
+                nf = ~f
+                if i >= max_step or nf.sum() == 0:
+                    break
+                walk = nrm - view / dot.unsqueeze(-1)
+                walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
+                walk = walk - sdf * nrm
+                cur[nf] += (step_size * walk)[tmp_nf]
+                i += 1
+            fin_parts.append(cur)
+            found_parts.append(f)
+        finish[mask] = torch.cat(fin_parts, dim=0)
+        found[mask] = torch.cat(found_parts, dim=0)
+        finish = finish.reshape(sh + [3])
+        found = found.reshape(sh)
+    edge_points = finish[found]
+    edge_mask = torch.zeros(cam.H, cam.W).bool()
+    edge_uv = torch.zeros_like(edge_points[..., :2])
+    upd = torch.zeros(0, dtype=torch.long)
+    if found.any():
+        edge_uv = project(cam, edge_points)
+        upd = torch.floor(edge_uv).long()
+        upd = upd[:, 1] * cam.W + upd[:, 0]
+        ok = (upd < cam.H * cam.W) & (upd >= 0)
+        upd, edge_points, edge_uv = upd[ok], edge_points[ok], edge_uv[ok]
+        if ok.any():
+            cnt = upd.shape[0]
+            upd, uidx = unique_first(upd)
+            uidx = torch.arange(cnt)[uidx]
+            edge_points = edge_points[uidx]
+            edge_uv = edge_uv[uidx]
+            edge_mask.view(-1)[upd] = True
+    return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": upd}
+
+
+@torch.no_grad()
+def raytrace_camera_full(scene: Scene, cam: CameraSpec, max_num_rays: int = 200000, fill_holes: bool = False,
+                         detect_edges: bool = False, prm: TracerParams = TracerParams(),
+                         depth_edge_mask: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """raytracer.py:542-590.  `depth_edge_mask` (optional) replaces the sobel-derived mask (used to pin the rest of the
+    chain to reference goldens, since kornia's sobel cannot run in the build container)."""
+    res = raytrace_camera(scene, cam, max_num_rays=max_num_rays, prm=prm)
+    if fill_holes:
+        depth = morph_closing3x3(res["depth"])
+        new_conv = depth > 1e-2
+        upd = new_conv & (~res["convergent_mask"])
+        if upd.any():
+            res["depth"][upd] = depth[upd]
+            res["convergent_mask"] = new_conv
+            res["distance"] = res["depth"] * res["ray_d_norm"]
+            res["points"] = res["ray_o"] + res["ray_d"] * res["distance"].unsqueeze(-1)
+    if detect_edges:
+        if depth_edge_mask is None:
+            depth_edge_mask = (sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+        res.update(locate_edge_points(scene, cam, res["points"], depth_edge_mask, max_step=16, step_size=1e-3,
+                                      dot_threshold=5e-2, max_num_rays=max_num_rays))
+        res["convergent_mask"] = res["convergent_mask"] & ~res["edge_mask"]
+    return res
+
+
+def render_edge_pixels(scene: Scene, results: Dict[str, Tensor], cam: CameraSpec, prm: TracerParams = TracerParams()) -> None:
+    """raytracer.py:665-729 (is_training=False): two side rays per edge pixel, area-weighted blend; mutates results."""
+    edge_points, edge_uv, edge_idx = results["edge_points"], results["edge_uv"], results["edge_pixel_idx"]
+    center = torch.floor(edge_uv) + 0.5
+    _, _, grads = sdf_get_all(scene.sdf_sd, scene.sdf_spec, edge_points)
+    nrm = grads / (grads.norm(dim=-1, keepdim=True) + 1e-10)
+    n2d = torch.matmul(nrm, cam.W2C[:3, :3].transpose(1, 0))[:, :2]
+    n2d = n2d / (n2d.norm(dim=-1, keepdim=True) + 1e-10)
+    radius = 0.707
+    pos_uv = center - radius * n2d
+    neg_uv = center + radius * n2d
+    dot2d = torch.sum((edge_uv - center) * n2d, dim=-1)
+    alpha = 2 * torch.arccos(torch.clamp(dot2d / radius, min=0.0, max=1.0))
+    w_pos = 1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)
+    pos = raytrace_pixels(scene, pos_uv, cam, prm=prm)
+    neg = raytrace_pixels(scene, neg_uv, cam, prm=prm)
+    render_normal_and_color(scene, pos)
+    render_normal_and_color(scene, neg)
+    color = pos["color"] * w_pos.unsqueeze(-1) + neg["color"] * (1.0 - w_pos.unsqueeze(-1))
+    results["color"].view(-1, 3)[edge_idx] = color
+    results["normal"].view(-1, 3)[edge_idx] = grads
+    results["edge_pos_neg_normal"] = torch.cat([pos["normal"][pos["convergent_mask"]], neg["normal"][neg["convergent_mask"]]], dim=0)
+    results["uv"].view(-1, 2)[edge_idx] = edge_uv
+    results["points"].view(-1, 3)[edge_idx] = edge_points
+
+
+def render_camera_full(scene: Scene, cam: CameraSpec, fill_holes: bool = False, handle_edges: bool = True,
+                       prm: TracerParams = TracerParams(), depth_edge_mask: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """raytracer.py:778-814 with is_training=False."""
+    res = raytrace_camera_full(scene, cam, max_num_rays=50000, fill_holes=fill_holes, detect_edges=handle_edges, prm=prm,
+                               depth_edge_mask=depth_edge_mask)
+    render_normal_and_color(scene, res, max_num_pts=320000)
+    if handle_edges and res["edge_mask"].sum() > 0:
+        render_edge_pixels(scene, res, cam, prm=prm)
+    return res
+
+
+# ----------------------------------------------------------------------------
 # algorithmic work (SURVEY 8d)
 # ----------------------------------------------------------------------------
 FLOP_PER_SDF_EVAL = 2 * (39 * 256 + 2 * 256 * 256 + 256 * 217 + 4 * 256 * 256 + 256 * 1)  # 918 016

@@ -38,7 +38,8 @@ sys.modules["icecream"].ic = lambda *a, **k: None
 
 from models.embedder import get_embedder  # noqa: E402  (reference)
 from models.fields import RenderingNetwork, SDFNetwork  # noqa: E402
-from models.raytracer import Camera, RayTracer, intersect_sphere, raytrace_camera, render_camera  # noqa: E402
+from models.raytracer import (Camera, RayTracer, intersect_sphere, locate_edge_points, raytrace_camera, render_camera,  # noqa: E402
+                              render_edge_pixels, render_normal_and_color)
 from models.renderer_ggx import GGXColocatedRenderer  # noqa: E402
 from models.rendering_func import get_materials  # noqa: E402
 
@@ -252,6 +253,41 @@ def main():
             meta["n_conv_%s_%s" % (scene, tag)] = int(out["n_conv"])
             print(scene, tag, "evals", trace_evals, "conv", int(out["n_conv"]),
                   "ref32~ref64 relL2", meta["ref32_vs_ref64_rel_l2_%s_%s" % (scene, tag)])
+
+    # ---- G8: silhouette handling.  kornia (closing / sobel) is absent, so raytrace_camera's
+    # fill_holes / detect_edges branches cannot run in the reference; what CAN be pinned is everything behind the
+    # sobel mask: locate_edge_points + render_edge_pixels are called from the reference with a depth-edge mask that
+    # the oracle's own (unpinned) sobel restatement produced and that is stored as an INPUT of the fixture.
+    from oracle import iron_ref as R  # the build's restatement: only for the unpinned sobel mask
+    for scene in ("S0", "S1"):
+        nets = build_reference_networks(scene)
+        sdf_net = nets["sdf_network"]
+        cam = fixture_camera(96, 96)
+        res = raytrace_camera(cam, sdf_net, tracer, max_num_rays=50000, fill_holes=False, detect_edges=False)
+        depth_edge_mask = (R.sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+        res.update(locate_edge_points(cam, res["points"], sdf_net, max_step=16, step_size=1e-3, dot_threshold=5e-2,
+                                      max_num_rays=50000, mask=depth_edge_mask))
+        res["convergent_mask"] &= ~res["edge_mask"]
+        fn = make_render_fn(nets, renderer, torch.float32)
+        render_normal_and_color(res, sdf_net, nets, fn, is_training=False, max_num_pts=320000)
+        before = {k: npf(res[k]).copy() for k in ("color", "normal", "points", "uv")}
+        # The reference's render_normal_and_color builds EMPTY tensors with `.cuda()` when a chunk has no hit
+        # (raytracer.py:627-633) -- the usual case for the outer side rays.  There is no GPU in this container, so for
+        # this one call Tensor.cuda is made the identity (the tensors are empty; nothing of the computation changes).
+        _cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            render_edge_pixels(res, cam, sdf_net, tracer, nets, fn, is_training=False)
+        finally:
+            torch.Tensor.cuda = _cuda
+        out = {k: npf(v) for k, v in res.items() if isinstance(v, torch.Tensor) and k not in ("ray_o",)}
+        out["depth_edge_mask_input"] = npf(depth_edge_mask)
+        for k, v in before.items():
+            out["pre_edge_" + k] = v
+        np.savez_compressed(os.path.join(HERE, "g8_edges_%s.npz" % scene), K=npf(cam.K), W2C=npf(cam.W2C), W=np.int64(cam.W),
+                            H=np.int64(cam.H), **out)
+        meta["n_edge_pixels_%s" % scene] = int(res["edge_mask"].sum())
+        print(scene, "edge pixels", int(res["edge_mask"].sum()), "of sobel candidates", int(depth_edge_mask.sum()))
 
     json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(meta, indent=1, sort_keys=True))

@@ -131,3 +131,40 @@ def test_result_dict_contract():
     for k, sh in want.items():
         assert tuple(res[k].shape) == sh, k
     assert res["convergent_mask"].dtype == torch.bool
+
+
+@pytest.mark.parametrize("scene", ["S0", "S1"])
+def test_g8_edge_walk_and_edge_blend(scene):
+    """Row f-1 behind the sobel mask: locate_edge_points + render_edge_pixels (raytracer.py:421-506, 665-729) vs the
+    reference, fed with the same depth-edge mask.  (closing / sobel themselves are parity-unpinned: kornia is absent.)"""
+    g = golden("g8_edges_%s.npz" % scene)
+    sc = oracle_scene(scenes.build_networks(scene), light=golden_meta()["light"])
+    cam = R.CameraSpec(int(g["W"]), int(g["H"]), t(g["K"]), t(g["W2C"]))
+    res = R.render_camera_full(sc, cam, fill_holes=False, handle_edges=True, depth_edge_mask=t(g["depth_edge_mask_input"]))
+    assert np.array_equal(res["edge_mask"].numpy(), g["edge_mask"])
+    assert np.array_equal(res["edge_pixel_idx"].numpy(), g["edge_pixel_idx"])
+    assert np.array_equal(res["convergent_mask"].numpy(), g["convergent_mask"])
+    np.testing.assert_allclose(res["edge_points"].numpy(), g["edge_points"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["edge_uv"].numpy(), g["edge_uv"], rtol=1e-5, atol=1e-4)
+    for k in ("color", "normal", "points", "uv"):
+        np.testing.assert_allclose(res[k].numpy(), g[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    assert res["edge_pos_neg_normal"].shape == g["edge_pos_neg_normal"].shape
+    # the edge pixels really were re-coloured
+    idx = g["edge_pixel_idx"]
+    assert np.abs(g["color"].reshape(-1, 3)[idx] - g["pre_edge_color"].reshape(-1, 3)[idx]).max() > 0
+
+
+def test_closing_and_sobel_restatements_selfcheck():
+    """Unpinned kornia restatements: internal consistency only (closing is extensive + idempotent, fills 1-px holes;
+    sobel is zero on constants, |grad| on ramps, replicate border)."""
+    torch.manual_seed(0)
+    x = (torch.rand(20, 24) > 0.3).float() * (1.0 + torch.rand(20, 24))
+    c = R.morph_closing3x3(x)
+    assert torch.all(c >= x)
+    assert torch.equal(R.morph_closing3x3(c), c)
+    h = torch.ones(9, 9); h[4, 4] = 0
+    assert torch.equal(R.morph_closing3x3(h), torch.ones(9, 9))
+    assert float(R.sobel_magnitude(torch.full((8, 8), 3.0)).max()) == pytest.approx(1e-3, rel=1e-3)
+    ramp = torch.arange(10.0).view(1, 10).expand(6, 10).contiguous() * 0.5
+    s = R.sobel_magnitude(ramp)
+    assert torch.allclose(s[:, 1:-1], torch.full((6, 8), (0.25 + 1e-6) ** 0.5))
