@@ -210,6 +210,21 @@ class SDFNetwork(_HipNet):
                                                     grad.data_ptr(), _lib.stream_ptr(xx.device)))
         return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])
 
+    @torch.no_grad()
+    def get_sdf_and_gradient(self, x: torch.Tensor):
+        """get_all without the feature rows (the edge walk, raytracer.py:453 / :683, discards them):
+        sdf [...,1], gradient [...,3]; skips the 256x256 feature layer."""
+        xx = _lib.require_cuda_f32(x.detach(), "x")
+        sh = list(xx.shape[:-1])
+        xx = xx.reshape(-1, 3)
+        n = xx.shape[0]
+        sdf = torch.empty((n, 1), dtype=torch.float32, device=xx.device)
+        grad = torch.empty((n, 3), dtype=torch.float32, device=xx.device)
+        with torch.cuda.device(xx.device):
+            _lib.check(_lib.load().iron_sdf_get_all(self.hip_net().handle, xx.data_ptr(), n, sdf.data_ptr(), None,
+                                                    grad.data_ptr(), _lib.stream_ptr(xx.device)))
+        return sdf.reshape(sh + [1]), grad.reshape(sh + [3])
+
 
 # IDR-style material MLP (reference: models/fields.py:141-239)
 class RenderingNetwork(_HipNet):

@@ -8,8 +8,9 @@ What differs is only HOW: one persistent kernel pipeline per call instead of a P
 masked torch ops (no host sync inside the tracer), and a fused shading kernel when the render_fn
 is the GGX one from iron_amd.rendering_func.
 
-Built: the forward path with fill_holes=False / handle_edges=False / is_training=False.
-Not built yet: hole filling, silhouette edge sampling, the backward pass.
+Built: the forward path (is_training=False) including hole filling and silhouette edge sampling
+(locate_edge_points :421-506, render_edge_pixels :665-729).
+Not built yet: the backward pass.
 There is no CPU path: tensors must be CUDA (ROCm) fp32.
 """
 from __future__ import annotations
@@ -269,14 +270,112 @@ def raytrace_pixels(sdf_network, raytracer, uv, camera, mask=None, max_num_rays=
     return merged
 
 
+def unique(x, dim=-1):
+    """raytracer.py:412-419: unique elements of x and, for each, the index of its FIRST occurrence in x."""
+    uniq, inverse = torch.unique(x, return_inverse=True, dim=dim)
+    perm = torch.arange(inverse.size(dim), dtype=inverse.dtype, device=inverse.device)
+    inverse, perm = inverse.flip([dim]), perm.flip([dim])
+    return uniq, inverse.new_empty(uniq.size(dim)).scatter_(dim, inverse, perm)
+
+
+def morph_closing3x3(depth):
+    """kornia.morphology.closing(depth[None,None], ones(3,3))[0,0] (raytracer.py:554-557) on an [H,W] image."""
+    x = _lib.require_cuda_f32(depth, "depth")
+    H, W = x.shape
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().iron_morph_closing3x3(x.data_ptr(), H, W, tmp.data_ptr(), out.data_ptr(),
+                                                     _lib.stream_ptr(x.device)))
+    return out
+
+
+def sobel_magnitude(depth):
+    """kornia.filters.sobel(depth[None,None])[0,0] (raytracer.py:569) on an [H,W] image."""
+    x = _lib.require_cuda_f32(depth, "depth")
+    H, W = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().iron_sobel_magnitude(x.data_ptr(), H, W, out.data_ptr(), _lib.stream_ptr(x.device)))
+    return out
+
+
 @torch.no_grad()
-def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=False, detect_edges=False):
-    """raytracer.py:542-590."""
-    if fill_holes or detect_edges:
-        raise NotImplementedError("fill_holes / detect_edges (kornia closing, sobel, edge walk) are SURVEY 8 row f-1, "
-                                  "not built in this round")
+def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_size, dot_threshold, max_num_rays=200000,
+                       mask=None):
+    """raytracer.py:421-506: walk the masked surface points along the surface towards the silhouette
+    (|n.v| <= dot_threshold), then keep one edge point per pixel.
+
+    Every point is an independent state machine (a found point is never moved again), so all candidates
+    advance together through <= max_step+1 get_all launches; `max_num_rays` has no effect on the result
+    (the reference only uses it to bound memory) and is accepted for signature parity."""
+    if mask is None:
+        mask = torch.ones_like(walk_start_points[..., 0]).bool()
+    dev = walk_start_points.device
+    cur = _lib.require_cuda_f32(walk_start_points[mask], "walk_start_points").reshape(-1, 3).clone()
+    found = torch.zeros(cur.shape[0], dtype=torch.bool, device=dev)
+    if cur.shape[0] > 0:
+        cam_o = camera.get_camera_origin().reshape(1, 3)
+        for i in range(max_step + 1):
+            sdf, grad = sdf_network.get_sdf_and_gradient(cur)
+            view = cam_o - cur
+            view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+            nrm = grad / (grad.norm(dim=-1, keepdim=True) + 1e-10)
+            dot = (nrm * view).sum(dim=-1)
+            # a found point keeps its position, hence its dot: OR-ing equals the reference's masked update
+            found |= dot.abs() <= dot_threshold
+            if i >= max_step or (i % 4 == 3 and bool(found.all())):
+                break
+            walk = nrm - view / dot.unsqueeze(-1)
+            walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
+            walk = walk - sdf * nrm
+            cur = torch.where(found.unsqueeze(-1), cur, cur + step_size * walk)
+    edge_points = cur[found]
+    edge_mask = camera.get_uv().new_zeros(camera.H, camera.W).bool()
+    edge_uv = torch.zeros_like(edge_points[..., :2])
+    update_pixels = torch.zeros(0, dtype=torch.long, device=dev)
+    if edge_points.shape[0] > 0:
+        edge_uv = camera.project(edge_points)
+        update_pixels = torch.floor(edge_uv.detach()).long()
+        update_pixels = update_pixels[:, 1] * camera.W + update_pixels[:, 0]
+        ok = (update_pixels < camera.H * camera.W) & (update_pixels >= 0)
+        update_pixels, edge_points, edge_uv = update_pixels[ok], edge_points[ok], edge_uv[ok]
+        if update_pixels.shape[0] > 0:
+            cnt = update_pixels.shape[0]
+            update_pixels, uidx = unique(update_pixels, dim=0)
+            uidx = torch.arange(cnt, device=dev)[uidx]
+            edge_points = edge_points[uidx]
+            edge_uv = edge_uv[uidx]
+            edge_mask.view(-1)[update_pixels] = True
+    return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
+
+
+@torch.no_grad()
+def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=False, detect_edges=False,
+                    depth_edge_mask=None):
+    """raytracer.py:542-590.  `depth_edge_mask` (extension, tests only) replaces the sobel-derived candidate mask."""
     results = raytrace_pixels(sdf_network, raytracer, camera.get_uv(), camera, max_num_rays=max_num_rays)
     results["depth"] *= results["convergent_mask"].float()
+
+    if fill_holes:
+        depth = morph_closing3x3(results["depth"])
+        new_convergent_mask = depth > 1e-2
+        update_mask = new_convergent_mask & (~results["convergent_mask"])
+        if update_mask.any():
+            results["depth"][update_mask] = depth[update_mask]
+            results["convergent_mask"] = new_convergent_mask
+            results["distance"] = results["depth"] * results["ray_d_norm"]
+            results["points"] = results["ray_o"] + results["ray_d"] * results["distance"].unsqueeze(-1)
+
+    if detect_edges:
+        depth_grad_norm = None
+        if depth_edge_mask is None:
+            depth_grad_norm = sobel_magnitude(results["depth"])
+            depth_edge_mask = (depth_grad_norm > 1e-2) & results["convergent_mask"]
+        results.update(locate_edge_points(camera, results["points"], sdf_network, max_step=16, step_size=1e-3,
+                                          dot_threshold=5e-2, max_num_rays=max_num_rays, mask=depth_edge_mask))
+        results["convergent_mask"] &= ~results["edge_mask"]
+        if VERBOSE_MODE and depth_grad_norm is not None:
+            results.update({"depth_grad_norm": depth_grad_norm, "depth_edge_mask": depth_edge_mask})
     return results
 
 
@@ -320,12 +419,48 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
         results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
 
 
+def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=False):
+    """raytracer.py:665-729: one ray on each side of every edge pixel, blended by the area the edge cuts off
+    the (circular, r = 0.707) pixel; mutates `results`."""
+    if is_training:
+        raise NotImplementedError("is_training=True (autograd through the HIP kernels) is SURVEY 8 row f-2")
+    edge_points, edge_uv, edge_pixel_idx = results["edge_points"], results["edge_uv"], results["edge_pixel_idx"]
+    edge_pixel_center = torch.floor(edge_uv) + 0.5
+
+    _, edge_grads = sdf_network.get_sdf_and_gradient(edge_points)
+    edge_normals = edge_grads / (edge_grads.norm(dim=-1, keepdim=True) + 1e-10)
+    edge_normals2d = torch.matmul(edge_normals, camera.W2C[:3, :3].transpose(1, 0))[:, :2]
+    edge_normals2d = edge_normals2d / (edge_normals2d.norm(dim=-1, keepdim=True) + 1e-10)
+
+    pixel_radius = 0.707
+    pos_side_uv = edge_pixel_center - pixel_radius * edge_normals2d
+    neg_side_uv = edge_pixel_center + pixel_radius * edge_normals2d
+    dot2d = torch.sum((edge_uv - edge_pixel_center) * edge_normals2d, dim=-1)
+    alpha = 2 * torch.arccos(torch.clamp(dot2d / pixel_radius, min=0.0, max=1.0))
+    pos_side_weight = 1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)
+
+    pos_side_results = raytrace_pixels(sdf_network, raytracer, pos_side_uv, camera)
+    neg_side_results = raytrace_pixels(sdf_network, raytracer, neg_side_uv, camera)
+    render_normal_and_color(pos_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
+    render_normal_and_color(neg_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
+
+    edge_color = (pos_side_results["color"] * pos_side_weight.unsqueeze(-1)
+                  + neg_side_results["color"] * (1.0 - pos_side_weight.unsqueeze(-1)))
+    results["color"].view(-1, 3)[edge_pixel_idx] = edge_color
+    results["normal"].view(-1, 3)[edge_pixel_idx] = edge_grads
+    results["edge_pos_neg_normal"] = torch.cat([pos_side_results["normal"][pos_side_results["convergent_mask"]],
+                                                neg_side_results["normal"][neg_side_results["convergent_mask"]]], dim=0)
+    results["uv"].view(-1, 2)[edge_pixel_idx] = edge_uv
+    results["points"].view(-1, 3)[edge_pixel_idx] = edge_points
+
+
 def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes=False, handle_edges=True,
-                  is_training=False):
-    """raytracer.py:778-814.  NB the reference defaults handle_edges=True; that branch (row f-1) is not built,
-    so callers must pass handle_edges=False explicitly -- it fails loudly rather than silently skipping."""
+                  is_training=False, depth_edge_mask=None):
+    """raytracer.py:778-814 (`depth_edge_mask`: see raytrace_camera)."""
     results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=50000, fill_holes=fill_holes,
-                              detect_edges=handle_edges)
+                              detect_edges=handle_edges, depth_edge_mask=depth_edge_mask)
     render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=is_training,
                             max_num_pts=320000)
+    if handle_edges and results["edge_mask"].sum() > 0:
+        render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=is_training)
     return results

@@ -129,9 +129,7 @@ def test_generic_render_fn_path_matches_fused():
         np.testing.assert_allclose(res2[k].cpu().numpy(), res[k].cpu().numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
 
 
-def test_handle_edges_and_training_fail_loudly():
+def test_training_fails_loudly():
     _, nets, cam, fn, _ = _render("S0", "c0")
-    with pytest.raises(NotImplementedError):
-        render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn)  # reference default handle_edges=True
     with pytest.raises(NotImplementedError):
         render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, handle_edges=False, is_training=True)
