@@ -91,11 +91,12 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("IRON_HIP_LIB") or LIB_PATH  # override: A/B of kernel variants (tools/variants.py)
+        if not os.path.exists(path):
             raise IronError(
                 "libiron_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
-                "g.build()'` (iron_amd has no CPU / eager fallback)" % LIB_PATH)
-        lib = C.CDLL(LIB_PATH)
+                "g.build()'` (iron_amd has no CPU / eager fallback)" % path)
+        lib = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res

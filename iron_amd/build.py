@@ -27,7 +27,14 @@ BASE_FLAGS = [
     # the pointwise glue must round like the reference's separate torch mul/add kernels
     "-ffp-contract=off",
     "-Wno-comment", "-Wno-unused-result",
+    # h2 core schedule (mlp_h2.h): fine-grained epilogue, opaque ring position, first fragment reads ahead of the refill
+    "-DIRON_H2_EPI3=1", "-DIRON_H2_OPAQUE_BT=1", "-DIRON_H2_FRAG_FIRST=1",
 ]
+
+# Accumulators of the h2 kernels in VGPRs (no v_accvgpr_read in front of the epilogue, 3-5x less scratch).  The pass
+# behind this option has crashed hipcc 7.2 on some revisions of trace.hip; a source that fails with it is recompiled
+# without it (the kernels are correct either way, only slower).
+OPTIONAL_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc() -> str:
@@ -44,7 +51,7 @@ def _digest(extra_flags) -> str:
         if os.path.exists(p):
             with open(p, "rb") as f:
                 h.update(f.read())
-    h.update(" ".join(BASE_FLAGS + list(extra_flags)).encode())
+    h.update(" ".join(BASE_FLAGS + OPTIONAL_FLAGS + list(extra_flags)).encode())
     return h.hexdigest()
 
 
@@ -61,8 +68,12 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + BASE_FLAGS + extra_flags + ["-c", os.path.join(CSRC, src), "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        tail = ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run([hipcc] + BASE_FLAGS + OPTIONAL_FLAGS + extra_flags + tail, capture_output=True, text=True)
+        if r.returncode != 0:
+            if verbose:
+                print("build: %s failed with %s, retrying without" % (src, " ".join(OPTIONAL_FLAGS)), file=sys.stderr)
+            r = subprocess.run([hipcc] + BASE_FLAGS + extra_flags + tail, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         return obj

@@ -10,6 +10,10 @@ namespace iron {
 #endif
 constexpr bool kFastActH = IRON_FAST_SOFTPLUS != 0;
 
+#if IRON_H2_STAMP
+__device__ unsigned long long g_h2_stamps[4 * kStampSteps * 8];
+#endif
+
 // x [n,3] -> out[n]: 4 waves x 32 points per pass
 __global__ __launch_bounds__(256, 1) void k_sdf_values_h2(H2StreamDev s, H2Meta m, const float* __restrict__ x, int64_t n,
                                                          float* __restrict__ out) {
@@ -30,7 +34,19 @@ __global__ __launch_bounds__(256, 1) void k_sdf_values_h2(H2StreamDev s, H2Meta 
         if (ok && lane < 32) out[idx] = v;
     }
     ring.drain();
+#if IRON_H2_STAMP
+    if (blockIdx.x == 0) {
+        const unsigned long long* st = reinterpret_cast<const unsigned long long*>(lds + kLdsStamp);
+        for (int i = threadIdx.x; i < 4 * kStampSteps * 8; i += 256) g_h2_stamps[i] = st[i];
+    }
+#endif
 }
+
+#if IRON_H2_STAMP
+extern "C" int iron_debug_h2_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_stamps), sizeof(unsigned long long) * 4 * kStampSteps * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool use_h2_core() {
     static int v = -1;
@@ -45,14 +61,14 @@ bool use_h2_core() {
 int launch_sdf_values_h2(const iron_net* net, const float* x, int64_t n, float* out, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_sdf_values_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total));
+        IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_sdf_values_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total + (IRON_H2_STAMP ? kLdsStampBytes : 0)));
         attr = true;
     }
     H2Meta m;
     m.n_hidden_layers = net->sdf.n_hidden_layers; m.skip_layer = net->sdf.skip_layer; m.scale = net->sdf.scale; m.b_last = net->sdf.b_last;
     const int64_t groups = (n + 127) / 128;
     const unsigned grid = (unsigned)(groups < 256 ? groups : 256);
-    hipLaunchKernelGGL(k_sdf_values_h2, dim3(grid), dim3(256), kLdsH2Total, st, net->h2_trace, m, x, n, out);
+    hipLaunchKernelGGL(k_sdf_values_h2, dim3(grid), dim3(256), kLdsH2Total + (IRON_H2_STAMP ? kLdsStampBytes : 0), st, net->h2_trace, m, x, n, out);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

@@ -19,6 +19,38 @@
 #include "iron_common.h"
 #include "mlp_core.h"
 
+// build-time switches (tools/variants.py A/B arms)
+#ifndef IRON_H2_EPI2
+#define IRON_H2_EPI2 0
+#endif
+#ifndef IRON_H2_EPI3
+#define IRON_H2_EPI3 0   // epilogue stages split over the three MFMA gaps of each k-step (implies the EPI2 arithmetic)
+#endif
+#ifndef IRON_H2_OPAQUE_BT
+#define IRON_H2_OPAQUE_BT 0
+#endif
+#ifndef IRON_H2_BUFDMA
+#define IRON_H2_BUFDMA 0
+#endif
+#ifndef IRON_H2_DMA_SPREAD
+#define IRON_H2_DMA_SPREAD 0   // refill instructions issued one per k-step (behind k-steps 1..8) instead of up front
+#endif
+#ifndef IRON_H2_FRAG_FIRST
+#define IRON_H2_FRAG_FIRST 0   // first fragment / bias reads issued BEFORE the refill instructions (their latency hides under them)
+#endif
+#ifndef IRON_H2_DMA_LATE
+#define IRON_H2_DMA_LATE 0
+#endif
+#ifndef IRON_H2_PREFETCH2
+#define IRON_H2_PREFETCH2 0
+#endif
+#ifndef IRON_H2_STAMP
+#define IRON_H2_STAMP 0   // diagnostic build: s_memtime stamps of one evaluation's ring steps (tools/stamps.py)
+#endif
+#ifndef IRON_H2_RING_AHEAD
+#define IRON_H2_RING_AHEAD 3
+#endif
+
 namespace iron {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -27,7 +59,7 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 constexpr int kRingSlots = 4;
 constexpr int kSlotBytes = 32768;
 constexpr int kRingBytes = kRingSlots * kSlotBytes;
-constexpr int kRingAhead = 3;            // slots in flight ahead of the one being consumed
+constexpr int kRingAhead = IRON_H2_RING_AHEAD;            // slots in flight ahead of the one being consumed
 constexpr int kLoadsPerSlot = 8;         // LDS-DMA instructions per wave and slot (head: 256 B each, hidden: 1 KiB each)
 constexpr float kLoScale = 2048.0f;
 constexpr float kLoInv = 1.0f / 2048.0f;
@@ -45,6 +77,21 @@ constexpr int kLdsTableBytes = 1024;
 constexpr int kLdsMisc = kLdsTable + kLdsTableBytes;    // per-wave flags etc.
 constexpr int kLdsMiscBytes = 256;
 constexpr int kLdsH2Total = kLdsMisc + kLdsMiscBytes;   // 144 640 B
+
+// diagnostic stamps: 8 x u64 per ring step and wave, staged in LDS behind the normal map (block 0 only)
+constexpr int kLdsStamp = kLdsH2Total;
+constexpr int kStampSteps = 72;
+constexpr int kStampFirst = 144;  // record steps [144, 216): the third evaluation of the 72-slot sequence
+constexpr int kLdsStampBytes = 4 * kStampSteps * 8 * 8;
+__device__ __forceinline__ void h2_stamp(unsigned long long* rec, int k) {
+#if IRON_H2_STAMP
+    if (rec) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) rec[k] = t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 
 __device__ __forceinline__ f32x16 mfma_h(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -116,14 +163,23 @@ __device__ __forceinline__ void split_head(const float* slots /*[24]*/, HeadFrag
 // hipcc otherwise orders every ds_read behind ALL pending LDS-DMA (it cannot see that they touch different ring
 // buffers) with an s_waitcnt vmcnt(0), which drains the prefetch.
 // ------------------------------------------------------------------------------------------------------
+// source of one slot refill: the weight stream as a buffer resource + the slot's (uniform) byte offset in it
+struct RingSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const char* gbase;
+    uint32_t off;
+};
+
 struct RingStep {
     const char* rd;     // LDS: the slot to consume
     char* wr;           // LDS: buffer to refill (the one the previous slot occupied)
-    const char* src;    // global: source of the refill, already offset by this lane
+    RingSrc src;        // global: source of the refill
     bool hidden;        // kind of the slot being refilled
+    unsigned long long* rec;  // diagnostic stamp record of this step (null unless IRON_H2_STAMP records it)
 };
 
 struct Ring {
+    __amdgpu_buffer_rsrc_t rsrc;
     const char* gbase;
     char* lds;
     unsigned long long mask_lo, mask_hi;  // bit q = 1: slot q is a hidden slot (32 KiB), 0: head slot (8 KiB)
@@ -133,17 +189,38 @@ struct Ring {
     int b_issue;          // ring buffer it goes to
     int b_take;           // ring buffer of the next slot to consume
     int wave, lane;
+    unsigned long long* stamps;  // diagnostic (IRON_H2_STAMP)
+    int n_step;
 
+    __device__ __forceinline__ unsigned long long* cur_rec() const {
+#if IRON_H2_STAMP
+        return (stamps && n_step >= kStampFirst && n_step < kStampFirst + kStampSteps) ? stamps + (n_step - kStampFirst) * 8 : nullptr;
+#else
+        return nullptr;
+#endif
+    }
     __device__ __forceinline__ bool kind_of(int q) const {
         const unsigned long long w = q < 64 ? mask_lo : mask_hi;
         return (w >> (q & 63)) & 1ull;
     }
     __device__ __forceinline__ RingStep step() {
         RingStep s;
+        s.rec = cur_rec();
+        ++n_step;
+        h2_stamp(s.rec, 0);  // after the barrier
         s.hidden = kind_of(q_issue);
-        s.src = gbase + off_issue + (s.hidden ? lane * 16 : lane * 4);
+        s.src.rsrc = rsrc;
+        s.src.gbase = gbase;
+        s.src.off = off_issue;
+        // The ring position is compile-time periodic after unrolling; hide that, or hipcc folds it into per-read
+        // absolute LDS addresses (> 16-bit immediates: one v_add per ds_read, plus AGPR parking of the CSE'd sums).
+        // As an opaque scalar the slot base is ONE v_add per step and every fragment read uses an immediate offset.
+        int bt = b_take;
+#if IRON_H2_OPAQUE_BT
+        asm volatile("" : "+s"(bt));
+#endif
         s.wr = lds + kLdsRing + b_issue * kSlotBytes;
-        s.rd = lds + kLdsRing + b_take * kSlotBytes;
+        s.rd = lds + kLdsRing + bt * kSlotBytes;
         off_issue += s.hidden ? (uint32_t)kSlotBytes : 8192u;
         if (++q_issue == n_slots) { q_issue = 0; off_issue = 0; }
         b_issue = (b_issue + 1) & (kRingSlots - 1);
@@ -151,7 +228,15 @@ struct Ring {
         return s;
     }
     __device__ __forceinline__ void sync() {
+        h2_stamp(cur_rec(), 5);  // arrival at the step boundary
+#if IRON_H2_RING_AHEAD == 3
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#elif IRON_H2_RING_AHEAD == 2
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+#error "ring depth"
+#endif
+        h2_stamp(cur_rec(), 6);  // own loads of this slot have landed
 #ifndef IRON_H2_NO_BARRIER  // timing experiment only
         __builtin_amdgcn_s_barrier();
 #endif
@@ -163,33 +248,87 @@ struct Ring {
     }
 };
 
-// this wave's 8 LDS-DMA instructions of one slot
-__device__ __forceinline__ void dma_issue(const char* src, char* __restrict__ wr, bool hidden, int wave) {
+// this wave's 8 LDS-DMA instructions of one slot: buffer loads with the lane offset in a VGPR and the fragment
+// offset in an SGPR (no 64-bit address arithmetic in the vector pipe)
+__device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__ wr, bool hidden, int wave) {
 #ifdef IRON_H2_NO_DMA  // timing experiment only: results are garbage
+    return;
+#endif
+    const int lane = threadIdx.x & 63;
+#if !IRON_H2_BUFDMA
+    const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
+    if (hidden) {
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            const int f = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
+                                             (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            const int f = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
+                                             (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+        }
+    }
     return;
 #endif
     if (hidden) {  // 32 fragments of 1 KiB; this wave moves fragments wave, wave+4, ...
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
-                                             (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 1024), 16,
+                                                     lane * 16, (int)(src.off + f * 1024), 0, 0);
         }
     } else {       // head slot: 8 KiB as 32 pieces of 256 B
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 256),
-                                             (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 256), 4,
+                                                     lane * 4, (int)(src.off + f * 256), 0, 0);
         }
     }
 }
 
+// instruction i (0..7) of this wave's refill of one slot
+__device__ __forceinline__ void dma_issue_one(const RingSrc& src, char* __restrict__ wr, bool hidden, int wave, int i) {
+#ifdef IRON_H2_NO_DMA
+    return;
+#endif
+    const int lane = threadIdx.x & 63;
+    const int f = wave + 4 * i;
+#if IRON_H2_BUFDMA
+    if (hidden)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 1024), 16,
+                                                 lane * 16, (int)(src.off + f * 1024), 0, 0);
+    else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 256), 4,
+                                                 lane * 4, (int)(src.off + f * 256), 0, 0);
+#else
+    const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
+    if (hidden)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
+                                         (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
+                                         (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ void ring_start(Ring& r, const H2StreamDev& s, char* lds_base, int wave, int lane) {
+    // the stream blob ends with the bias / row tables; 1 MiB of slack keeps num_records valid for every offset used
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(s.base), 0, 0x7fffffff, 0x00020000);
     r.gbase = s.base; r.lds = lds_base; r.n_slots = (int)s.n_slots;
     r.mask_lo = (unsigned long long)s.kind_mask[0] | ((unsigned long long)s.kind_mask[1] << 32);
     r.mask_hi = (unsigned long long)s.kind_mask[2] | ((unsigned long long)s.kind_mask[3] << 32);
     r.q_issue = 0; r.off_issue = 0; r.b_issue = 0; r.b_take = 0; r.wave = wave; r.lane = lane;
+    r.n_step = -kRingAhead;  // the start-up steps below are not ring steps
+#if IRON_H2_STAMP
+    r.stamps = blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(lds_base + kLdsStamp) + wave * kStampSteps * 8 : nullptr;
+#else
+    r.stamps = nullptr;
+#endif
     for (int i = 0; i < kRingAhead; ++i) {
         RingStep st = r.step();
         dma_issue(st.src, st.wr, st.hidden, wave);
@@ -237,7 +376,7 @@ __device__ __forceinline__ f32x16 h2_combine(const f32x16& hi, const f32x16& lo)
 
 // One ring step on a head slot: fragments [k-step 0..2][piece hi, lo] (+ padding)
 __device__ __forceinline__ void step_head(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
-                                          const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
+                                          const RingSrc& src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
                                           const HeadFrag& hd, f32x16& acc_hi, f32x16& acc_lo) {
     dma_issue(src, wr, src_hidden, wave);
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
@@ -249,6 +388,30 @@ __device__ __forceinline__ void step_head(const char* __restrict__ rd, const cha
         acc_lo = mfma_h(wh, hd.l[ks], acc_lo);
         acc_lo = mfma_h(wl, hd.h[ks], acc_lo);
     }
+}
+
+// (x0, x1) -> packed fp16 pair, round to nearest: v_cvt_pk_f16_f32
+__device__ __forceinline__ f16x2 cvt_pk_rn(float x0, float x1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v;
+    v[0] = x0;
+    v[1] = x1;
+    return __builtin_convertvector(v, f16x2);
+}
+
+// max(x, 0) as one v_med3_f32 (fmaxf would add a canonicalising v_max x, x, x in IEEE mode)
+__device__ __forceinline__ float relu_med3(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
+
+// x - f32(h) with the fp16 operand read in place (low / high half of a packed pair): v_fma_mix_f32, exact
+__device__ __forceinline__ float residual_lo(unsigned hpair, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float residual_hi(unsigned hpair, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+    return r;
 }
 
 // Empty asm statements that take values as read-write operands: they are chained to the side-effect order (barriers,
@@ -264,6 +427,66 @@ __device__ __forceinline__ void h2_epilogue_split(const f32x16& hi, const f32x16
     split_tile(softplus_tile<FAST>(h2_combine(hi, lo)), out);
 }
 
+// ---- fine-grained epilogue (IRON_H2_EPI3) ------------------------------------------------------------
+// Pipeline state of one pending output tile.  Stage `ks` of the 16-stage pipeline is cut into three parts, one per
+// MFMA gap of k-step ks, so that no gap carries more than ~6 VALU issue slots (an MFMA leaves 24 of its 32 cycles
+// to the vector issue port; MI355X_MICROARCH.md).
+struct EpiState {
+    float z[16], e[16], rr[16];
+    unsigned hpb[8];
+    u32x4 oh[2], ol[2];
+};
+
+__device__ __forceinline__ void pin1(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin1u(unsigned& a) { asm volatile("" : "+v"(a)); }
+
+// element range of part `part` (0..2) of an n-element stage: 16 -> 5/6/5, 8 -> 3/3/2
+__device__ __forceinline__ constexpr int epi_lo(int n, int part) { return n == 16 ? (part == 0 ? 0 : part == 1 ? 5 : 11) : (part == 0 ? 0 : part == 1 ? 3 : 6); }
+__device__ __forceinline__ constexpr int epi_hi(int n, int part) { return n == 16 ? (part == 0 ? 5 : part == 1 ? 11 : 16) : (part == 0 ? 3 : part == 1 ? 6 : 8); }
+
+template <int EPI, int ACT>
+__device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const f32x16& p_hi, const f32x16& p_lo) {
+    constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
+    constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
+    const int a16 = epi_lo(16, part), b16 = epi_hi(16, part), a8 = epi_lo(8, part), b8 = epi_hi(8, part);
+    if (ks == 0) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin1(st.z[i]); } }
+    if constexpr (ACT == 0) {
+        if (ks == 1) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.e[i] = __builtin_fabsf(st.z[i]) * -kC1; pin1(st.e[i]); } }
+        if (ks == 2) { _Pragma("unroll") for (int i = a8; i < b8; ++i) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); pin1(st.e[i]); } }
+        if (ks == 3) { _Pragma("unroll") for (int i = 8 + a8; i < 8 + b8; ++i) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); pin1(st.e[i]); } }
+        if (ks == 4) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.e[i] = 1.0f + st.e[i]; pin1(st.e[i]); } }
+        if (ks == 5) { _Pragma("unroll") for (int i = a8; i < b8; ++i) { st.e[i] = __builtin_amdgcn_logf(st.e[i]); pin1(st.e[i]); } }
+        if (ks == 6) { _Pragma("unroll") for (int i = 8 + a8; i < 8 + b8; ++i) { st.e[i] = __builtin_amdgcn_logf(st.e[i]); pin1(st.e[i]); } }
+        if (ks == 7) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
+        if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = __builtin_fmaf(st.e[i], kC2, st.z[i]); pin1(st.z[i]); } }
+    } else {
+        if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
+    }
+    if constexpr (EPI == 1) {
+        if (ks == 9) {
+            _Pragma("unroll") for (int q = a8; q < b8; ++q) {
+                st.hpb[q] = __builtin_bit_cast(unsigned, cvt_pk_rn(st.z[2 * q], st.z[2 * q + 1]));
+                pin1u(st.hpb[q]);
+            }
+        }
+        if (ks == 10) {
+            _Pragma("unroll") for (int i = a16; i < b16; ++i) {
+                st.rr[i] = (i & 1) ? residual_hi(st.hpb[i >> 1], st.z[i]) : residual_lo(st.hpb[i >> 1], st.z[i]);
+                pin1(st.rr[i]);
+            }
+        }
+        if (ks == 11) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.rr[i] = st.rr[i] * kLoScale; pin1(st.rr[i]); } }
+        if (ks == 12) {
+            _Pragma("unroll") for (int q = a8; q < b8; ++q) {
+                unsigned lp = __builtin_bit_cast(unsigned, cvt_pk_rn(st.rr[2 * q], st.rr[2 * q + 1]));
+                pin1u(lp);
+                st.oh[q >> 2][q & 3] = st.hpb[q];
+                st.ol[q >> 2][q & 3] = lp;
+            }
+        }
+    }
+}
+
 // One ring step on a hidden slot, fused with the epilogue of the previous output tile:
 //   refill `wr`;  acc += W[tile,:] * in  (48 MFMAs, fragment reads one k-step ahead);  meanwhile (VALU) the pending
 //   accumulators `p_hi/p_lo` of tile-1 go through combine + softplus (+ fp16 split) into out_prev / hf_prev.
@@ -273,12 +496,28 @@ __device__ __forceinline__ void h2_epilogue_split(const f32x16& hi, const f32x16
 // ACT: 0 = softplus(beta=100) (SDF net), 1 = relu (material nets).
 template <bool FAST, int EPI, int ACT = 0>
 __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
-                                            const char* src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
+                                            const RingSrc& src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
                                             const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
-                                            const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev) {
-    dma_issue(src, wr, src_hidden, wave);
+                                            const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev,
+                                            unsigned long long* rec = nullptr) {
+#if IRON_H2_FRAG_FIRST
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
     half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_issue(src, wr, src_hidden, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    h2_stamp(rec, 1);  // refill issued
+#else
+#if !IRON_H2_DMA_LATE && !IRON_H2_DMA_SPREAD
+    dma_issue(src, wr, src_hidden, wave);
+#endif
+    h2_stamp(rec, 1);  // refill issued
+    if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
+    half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
+#endif
+#if IRON_H2_PREFETCH2
+    half8 gh = lds_frag(rd, 2, lane), gl = lds_frag(rd, 3, lane);  // fragments run TWO k-steps ahead of their MFMAs
+#endif
     // The previous tile's epilogue runs as a 16-stage software pipeline, one stage per k-step, each stage applied
     // to all 16 elements of the tile: a stage is 8..16 INDEPENDENT VALU ops (~70-90 issue cycles) placed behind the
     // k-step's three MFMAs (96 cycles in the matrix pipe), and it consumes what the previous stage produced a whole
@@ -287,24 +526,97 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     float z[16], e[16], hb[16], rr[16];
     f16x2 hp[8];
     u32x4 oh[2], ol[2];
+#if IRON_H2_EPI3
+    EpiState es;
+#endif
     constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
     constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
+#if IRON_H2_PREFETCH2
+        half8 nh = gh, nl = gl;
+        if (ks < 14) {
+            nh = lds_frag(rd, 2 * ks + 4, lane);
+            nl = lds_frag(rd, 2 * ks + 5, lane);
+        }
+#else
         half8 nh = fh, nl = fl;
         if (ks < 15) {  // next k-step's fragments: in flight while this step's MFMAs run
             nh = lds_frag(rd, 2 * ks + 2, lane);
             nl = lds_frag(rd, 2 * ks + 3, lane);
         }
+#endif
         const int ti = ks >> 1, s = ks & 1;
+#if IRON_H2_EPI3
+        acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
+        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
+        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
+        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
+#else
         acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
         acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
+#endif
+#if IRON_H2_DMA_LATE
+        if (ks == 0) dma_issue(src, wr, src_hidden, wave);  // refill issued behind the first k-step's MFMAs
+#endif
+#if IRON_H2_DMA_SPREAD
+        if (ks >= 1 && ks <= kLoadsPerSlot) dma_issue_one(src, wr, src_hidden, wave, ks - 1);
+#endif
+#if IRON_H2_PREFETCH2
+        fh = gh; fl = gl; gh = nh; gl = nl;
+#else
         fh = nh;
         fl = nl;
+#endif
+#if !IRON_H2_EPI3
         if constexpr (EPI != 0) {
             static_assert(FAST, "the staged epilogue implements the v_exp/v_log softplus");
             if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin16(z); }
+#if IRON_H2_EPI2
+            // softplus_100(z) = max(z, 0) + log2(1 + 2^(-|z| * 100 log2 e)) * ln2 / 100: one multiply (source modifiers
+            // carry the -|.|), no overflow for any z, no select
+            if constexpr (ACT == 0) {
+                if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = __builtin_fabsf(z[i]) * -kC1; pin16(e); }
+                if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
+                if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
+                if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
+                if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
+                if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
+                if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = relu_med3(z[i]); pin16(z); }
+                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = __builtin_fmaf(e[i], kC2, z[i]); pin16(z); }
+            } else {
+                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = relu_med3(z[i]); pin16(z); }
+            }
+            if constexpr (EPI == 1) {
+                // hi halves: ONE packed conversion per pair; the residual z - hi comes from v_fma_mix (f16 source read in
+                // place), then the 2^11 scale and the second packed conversion
+                if (ks == 9) {
+                    unsigned hb8[8];
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) hb8[i] = __builtin_bit_cast(unsigned, cvt_pk_rn(z[2 * i], z[2 * i + 1]));
+                    asm volatile("" : "+v"(hb8[0]), "+v"(hb8[1]), "+v"(hb8[2]), "+v"(hb8[3]), "+v"(hb8[4]), "+v"(hb8[5]), "+v"(hb8[6]), "+v"(hb8[7]));
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) hp[i] = __builtin_bit_cast(f16x2, hb8[i]);
+                }
+                if (ks == 10) {
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+                        const unsigned hb = __builtin_bit_cast(unsigned, hp[i]);
+                        rr[2 * i] = residual_lo(hb, z[2 * i]);
+                        rr[2 * i + 1] = residual_hi(hb, z[2 * i + 1]);
+                    }
+                    pin16(rr);
+                }
+                if (ks == 11) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = rr[i] * kLoScale; pin16(rr); }
+                if (ks == 12) {
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+                        const f16x2 lp = cvt_pk_rn(rr[2 * i], rr[2 * i + 1]);
+                        oh[i >> 2][i & 3] = __builtin_bit_cast(unsigned, hp[i]);
+                        ol[i >> 2][i & 3] = __builtin_bit_cast(unsigned, lp);
+                    }
+                }
+            }
+#else
             if constexpr (ACT == 0) {
                 if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = z[i] * kC1; pin16(e); }
                 if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
@@ -335,9 +647,18 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
                     }
                 }
             }
+#endif
         }
+#endif  // !IRON_H2_EPI3
         __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) h2_stamp(rec, 2);
+        if (ks == 7) h2_stamp(rec, 3);
+        if (ks == 15) h2_stamp(rec, 4);
     }
+#if IRON_H2_EPI3
+    if constexpr (EPI == 1) { oh[0] = es.oh[0]; oh[1] = es.oh[1]; ol[0] = es.ol[0]; ol[1] = es.ol[1]; }
+    if constexpr (EPI == 2) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = es.z[i]; }
+#endif
     if constexpr (EPI == 1) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -379,13 +700,13 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
         const RingStep st = ring.step();                                                                                   \
         if constexpr ((TO) == 0)                                                                                           \
             step_hidden<FAST, 0, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
-                                 acc[Q][0], acc[Q][1], dummy_out, dummy_hf);                                               \
+                                 acc[Q][0], acc[Q][1], dummy_out, dummy_hf, st.rec);                                       \
         else if constexpr (LAST)                                                                                           \
             step_hidden<FAST, 2, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
-                                 acc[Q][0], acc[Q][1], dummy_out, hf[(TO) > 0 ? (TO) - 1 : 0]);                            \
+                                 acc[Q][0], acc[Q][1], dummy_out, hf[(TO) > 0 ? (TO) - 1 : 0], st.rec);                    \
         else                                                                                                               \
             step_hidden<FAST, 1, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
-                                 acc[Q][0], acc[Q][1], out[(TO) > 0 ? (TO) - 1 : 0], dummy_hf);                            \
+                                 acc[Q][0], acc[Q][1], out[(TO) > 0 ? (TO) - 1 : 0], dummy_hf, st.rec);                    \
     }
     IRON_H2_TILE(0) IRON_H2_TILE(1) IRON_H2_TILE(2) IRON_H2_TILE(3)
     IRON_H2_TILE(4) IRON_H2_TILE(5) IRON_H2_TILE(6) IRON_H2_TILE(7)
