@@ -507,6 +507,7 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     dma_issue(src, wr, src_hidden, wave);
     __builtin_amdgcn_sched_barrier(0);
     h2_stamp(rec, 1);  // refill issued
+    h2_stamp(rec, 7);  // calibration: what a stamp itself costs at this point
 #else
 #if !IRON_H2_DMA_LATE && !IRON_H2_DMA_SPREAD
     dma_issue(src, wr, src_hidden, wave);

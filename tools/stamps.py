@@ -25,7 +25,7 @@ assert fn(buf) == 0
 a = np.array(buf[:], dtype=np.uint64).reshape(4, 72, 8).astype(np.int64)
 t0 = a[:, 0, 0].min()
 print("step kind |  per wave: barrier-wait  refill-issue  ks0  ks1-7  ks8-15 | step total (wave 0)")
-tot = np.zeros(6)
+tot = np.zeros(7)
 for q in range(72):
     row = []
     for w in range(4):
@@ -33,13 +33,13 @@ for q in range(72):
         nxt = a[w, q + 1] if q + 1 < 72 else None
         bw = r[0] - r[6] if r[6] else 0          # barrier wait of THIS step (stamps 5,6 precede stamp 0 of the same step)
         vw = r[6] - r[5] if r[5] else 0          # vmcnt wait
-        row.append((vw, bw, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]))
+        row.append((vw, bw, r[1] - r[0], r[2] - r[7], r[3] - r[2], r[4] - r[3], r[7] - r[1]))
     row = np.array(row)
     hidden = a[0, q, 4] != 0
     if hidden:
         tot += row.mean(axis=0)
     span = (a[0, q + 1, 0] - a[0, q, 0]) if q + 1 < 72 else 0
-    print("%2d %s | vmw %s  bar %s  dma %s  ks0 %s  ks1-7 %s  ks8-15 %s | %d" % (
-        q, "H" if hidden else "h", *[str(row[:, i].tolist()) for i in range(6)], span))
+    print("%2d %s | vmw %s  bar %s  dma %s  ks0 %s  ks1-7 %s  ks8-15 %s  stamp-cost %s | %d" % (
+        q, "H" if hidden else "h", *[str(row[:, i].tolist()) for i in range(7)], span))
 print("hidden-step means (vmcnt wait, barrier wait, refill issue, ks0, ks1-7, ks8-15):", (tot / 64).round(0).tolist())
 print("evaluation span (wave 0): %d cycles" % (a[0, 71, 4] - a[0, 0, 0]))

@@ -22,18 +22,29 @@ def build(name, flags):
     from iron_amd import build as B
     os.makedirs(os.path.join(VDIR, name), exist_ok=True)
     hipcc = B._hipcc()
-    objs = []
-    procs = []
     only = [x for x in os.environ.get("VARIANT_ONLY", "").split(",") if x]  # restrict the flags to these sources
-    for src in B.SOURCES:
+    objs, procs = [], []
+
+    def start(src, fl):
         obj = os.path.join(VDIR, name, src.replace(".hip", ".o"))
-        objs.append(obj)
+        return obj, subprocess.Popen([hipcc] + B.BASE_FLAGS + fl + ["-c", os.path.join(B.CSRC, src), "-o", obj],
+                                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    for src in B.SOURCES:
         fl = list(flags) if (not only or src in only) else []
-        procs.append(subprocess.Popen([hipcc] + B.BASE_FLAGS + fl + ["-c", os.path.join(B.CSRC, src), "-o", obj],
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    for p in procs:
+        obj, p = start(src, fl)
+        objs.append(obj)
+        procs.append((src, fl, p))
+    for src, fl, p in procs:
         out = p.communicate()[0]
-        if p.returncode != 0:
+        if p.returncode != 0 and "-amdgpu-mfma-vgpr-form=1" in fl:  # same fallback as iron_amd/build.py
+            print("  %s: hipcc failed with the vgpr-form option, recompiling without" % src)
+            fl2 = [f for i, f in enumerate(fl) if f != "-amdgpu-mfma-vgpr-form=1" and not (f == "-mllvm" and fl[i + 1] == "-amdgpu-mfma-vgpr-form=1")]
+            _, p2 = start(src, fl2)
+            out = p2.communicate()[0]
+            if p2.returncode != 0:
+                sys.exit(out)
+        elif p.returncode != 0:
             sys.exit(out)
     lib = os.path.join(VDIR, "libiron_hip_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
