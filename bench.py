@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--scene", default="S0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--edges", action="store_true",
+                    help="N=1 only: fill_holes=True, handle_edges=True (the reference's validation render, SURVEY row f-1) "
+                         "instead of the headline configuration")
     ap.add_argument("--cpu-sample-res", type=int, default=160)
     return ap.parse_args()
 
@@ -120,7 +123,8 @@ def main():
         if world == 1:
             rt.VERBOSE_MODE = stats
             try:
-                return render_camera(cams[0], sdf, tracer, nets, fn, fill_holes=False, handle_edges=False, is_training=False)
+                return render_camera(cams[0], sdf, tracer, nets, fn, fill_holes=a.edges and not stats, handle_edges=a.edges and not stats,
+                                     is_training=False)  # the work counters are read on the plain trace
             finally:
                 rt.VERBOSE_MODE = False
         return sharded.render(cams, collect_stats=stats)
@@ -188,34 +192,52 @@ def main():
                 kernels[k] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
         dom = max(kernels, key=lambda k: kernels[k]["ms_total"]) if kernels else None
         roof = None
+        if a.edges:
+            dom = None  # per-kernel averages mix the full-image launches with the small edge-ray launches: no roofline line
         if dom and alg.get(dom):
             avg_s = kernels[dom]["ms_avg"] / 1e3
-            ach = alg[dom] / avg_s
             traffic = None
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get(dom, {}).get("bytes_per_launch")
             core = os.environ.get("IRON_MLP_CORE", "h2")
+            h2 = core.startswith("h")
+            # units one launch processes = the SDF evaluations the kernel EXECUTES (the sampler stops at a ray's first
+            # negative block, so it executes fewer than the reference's 128 per ray; those are NOT credited here)
             exec_evals = {"sphere": E_sphere, "sampler": E_hip - E_sphere - n_bisect * 9}.get(dom)
+            if exec_evals is not None:
+                flop_launch = FLOP_PER_EVAL * exec_evals / world
+            else:
+                flop_launch = alg[dom]
+            ach = flop_launch / avg_s
+            # fp32-accurate MACs on the f16 pipe cost three MFMA products each: the pipe's ceiling for this arithmetic is
+            # its dense f16 peak / 3.  The exact-fp32 core (IRON_MLP_CORE=f32) is priced against the fp32 MFMA peak.
+            peak = PEAK_F16_MFMA / 3.0 if h2 else PEAK_FP32_MFMA
             executed = None
-            if exec_evals is not None and dom in ("sphere", "sampler"):
-                per = MFMA_FLOP_PER_EVAL_H2 if core.startswith("h") else MFMA_FLOP_PER_EVAL_F32
-                pk = PEAK_F16_MFMA if core.startswith("h") else PEAK_FP32_MFMA
+            if exec_evals is not None:
+                per = MFMA_FLOP_PER_EVAL_H2 if h2 else MFMA_FLOP_PER_EVAL_F32
+                pk = PEAK_F16_MFMA if h2 else PEAK_FP32_MFMA
                 ex = per * exec_evals / world / avg_s
-                executed = {"mfma_tflops": ex / 1e12, "pipe": "f16 (fp32 = 2 x fp16 split, 3 products)" if core.startswith("h") else "f32",
+                executed = {"mfma_tflops": ex / 1e12, "pipe": "f16 (fp32 = 2 x fp16 split, 3 products)" if h2 else "f32",
                             "pipe_peak": pk / 1e12, "frac_of_pipe_peak": ex / pk}
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA, "traffic": traffic, "core": core, "executed": executed,
-                    "algorithmic_flop_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["ms_avg"],
-                    "note": "algorithmic FLOP = 918016 x the evaluations the REFERENCE makes for this kernel's rays "
-                            "(the sampler stops at the first negative block, so it executes fewer)"}
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": traffic, "core": core,
+                    "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate MAC" if h2
+                                   else "dense fp32 MFMA 157.3 TFLOP/s"),
+                    "vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA, "executed": executed,
+                    "algorithmic_flop_per_launch": flop_launch, "units_per_launch": exec_evals / world if exec_evals is not None else None,
+                    "flop_per_unit": FLOP_PER_EVAL, "avg_launch_ms": kernels[dom]["ms_avg"],
+                    "reference_equivalent_tflops": alg[dom] / avg_s / 1e12,
+                    "note": "achieved = 918016 FLOP x SDF evaluations the kernel executes / launch time (hipEvents on the "
+                            "launch stream); reference_equivalent also credits the evaluations the reference makes and "
+                            "the kernel's early exit skips"}
         out = {
             "metric": "Mrays/s sphere-trace+GGX shade, drv/dragon 800x800 (synthetic S0)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mlp_core": os.environ.get("IRON_MLP_CORE", "h2") + (" (fp32-accurate split-fp16 MFMA, LDS weight ring)" if not os.environ.get("IRON_MLP_CORE", "h2").startswith("f") else " (exact fp32 MFMA)"),
             "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
-                                   "sphere-trace + GGX shade, fp32" % (a.scene, a.res, a.res),
+                                   "sphere-trace + GGX shade, fp32%s" % (a.scene, a.res, a.res, " + hole filling + silhouette edge sampling" if a.edges else ""),
                        "views_per_step": n_views, "rays_per_step": rays,
                        "sharding": "none (render_camera)" if world == 1 else "interleaved 32x32 tiles over %d ranks, RCCL gather" % world,
                        "tracer": {"sdf_threshold": 5e-5, "sphere_tracing_iters": 16, "n_steps": 128, "chunk": 50000}},
