@@ -1,4 +1,4 @@
-"""The `ggx` branch of the reference's network factory (models/network_conf.py:16-44, 72-122,
+"""The `ggx` and `comp2` branches of the reference's network factory (models/network_conf.py:16-44, 72-122, 318-447,
 748-764), restated for this path: network shapes are the spec the HIP kernels are built for.
 """
 from __future__ import annotations
@@ -32,10 +32,33 @@ def init_sdf_network_dict(device="cuda"):
                       geometric_init=True, weight_norm=True).to(device)
 
 
+COMP_NETWORKS = ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "metallic_network",
+                 "dielectric_network", "metallic_eta_network", "metallic_k_network", "dielectric_eta_network")
+
+
+def comp_material_network(name: str) -> RenderingNetwork:
+    """One material network of the `comp2` branch (models/network_conf.py:330-445): the diffuse head is the IDR-style
+    net of the ggx branch; every other head is a no_view_dir PE-6 net with output_scale 1 and bias 0.1 (albedo: 0)."""
+    if name == "diffuse_albedo_network":
+        return RenderingNetwork(d_in=9, d_out=3, d_feature=256, d_hidden=256, n_layers=4, multires_view=4, mode="idr",
+                                squeeze_out=True)
+    if name not in COMP_NETWORKS:
+        raise KeyError(name)
+    d_out, bias = (3, 0.0) if name == "specular_albedo_network" else (1, 0.1)
+    return RenderingNetwork(d_in=6, d_out=d_out, d_feature=256, d_hidden=256, n_layers=4, multires=6, multires_view=-1,
+                            mode="no_view_dir", squeeze_out=False, output_bias=bias, output_scale=1.0)
+
+
 def init_rendering_network_dict(renderer_name="ggx", device="cuda"):
-    """models/network_conf.py:47-122, `ggx` branch (the fork's other branches are out of scope)."""
+    """models/network_conf.py:47-122 (`ggx`) and :318-447 (`comp2`; `comp`, which render_surface.py:107 asks for, is not
+    defined by the reference's factory and is served by the same shapes).  color_network / env_light_network of the
+    comp2 dict are not consumed by the render path and are not built."""
+    if renderer_name in ("comp", "comp2"):
+        d = {name: comp_material_network(name).to(device) for name in COMP_NETWORKS}
+        d["point_light_network"] = PointLightNetwork().to(device)
+        return d
     if renderer_name != "ggx":
-        raise NotImplementedError("only the 'ggx' renderer is built (SURVEY 8 row f-4 covers the others)")
+        raise NotImplementedError("renderer %r: only 'ggx' and 'comp'/'comp2' are built" % renderer_name)
     return {
         "diffuse_albedo_network": RenderingNetwork(d_in=9, d_out=3, d_feature=256, d_hidden=256, n_layers=4,
                                                    multires_view=4, mode="idr", squeeze_out=True).to(device),
@@ -51,8 +74,10 @@ def init_rendering_network_dict(renderer_name="ggx", device="cuda"):
 
 def choose_renderer(renderer_name="ggx"):
     """models/network_conf.py:748-764."""
-    from .renderer_ggx import GGXColocatedRenderer
+    from .renderer_ggx import CompositeRenderer, GGXColocatedRenderer
 
+    if renderer_name in ("comp", "comp2"):
+        return CompositeRenderer(use_cuda=True)
     if renderer_name != "ggx":
-        raise NotImplementedError("only the 'ggx' renderer is built")
+        raise NotImplementedError("renderer %r: only 'ggx' and 'comp'/'comp2' are built" % renderer_name)
     return GGXColocatedRenderer(use_cuda=True)

@@ -439,10 +439,22 @@ def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_di
     alpha = 2 * torch.arccos(torch.clamp(dot2d / pixel_radius, min=0.0, max=1.0))
     pos_side_weight = 1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)
 
-    pos_side_results = raytrace_pixels(sdf_network, raytracer, pos_side_uv, camera)
-    neg_side_results = raytrace_pixels(sdf_network, raytracer, neg_side_uv, camera)
-    render_normal_and_color(pos_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
-    render_normal_and_color(neg_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
+    n_edge = edge_uv.shape[0]
+    if 0 < n_edge <= 200000:
+        # Both side-ray batches through ONE launch sequence: with chunk = n_edge the tracer treats rays [0, n) and
+        # [n, 2n) as two separate reference calls (own bisection counts, raytracer.py:204-217), and shading is
+        # per point, so this equals the reference's two raytrace_pixels + two render_normal_and_color calls while
+        # halving the chain of small dependent launches.
+        both = raytrace_pixels(sdf_network, raytracer, torch.cat([pos_side_uv, neg_side_uv], dim=0), camera,
+                               max_num_rays=n_edge)
+        render_normal_and_color(both, sdf_network, color_network_dict, render_fn, is_training=is_training)
+        pos_side_results = {k: v[:n_edge] for k, v in both.items()}
+        neg_side_results = {k: v[n_edge:] for k, v in both.items()}
+    else:
+        pos_side_results = raytrace_pixels(sdf_network, raytracer, pos_side_uv, camera)
+        neg_side_results = raytrace_pixels(sdf_network, raytracer, neg_side_uv, camera)
+        render_normal_and_color(pos_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
+        render_normal_and_color(neg_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
 
     edge_color = (pos_side_results["color"] * pos_side_weight.unsqueeze(-1)
                   + neg_side_results["color"] * (1.0 - pos_side_weight.unsqueeze(-1)))

@@ -54,6 +54,24 @@ def build_networks(scene: str = "S0", seed: int = 0) -> Dict[str, torch.nn.Modul
     return nets
 
 
+COMP_ORDER = ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "metallic_network",
+              "dielectric_network", "metallic_eta_network", "metallic_k_network", "dielectric_eta_network")
+
+
+def build_comp_networks(seed: int = 0) -> Dict[str, torch.nn.Module]:
+    """Scene S2: the seed-0 SDF network of S0, then the `comp2` material networks of
+    models/network_conf.py:318-447 in COMP_ORDER (the construction order fixes the RNG stream)."""
+    from .network_conf import comp_material_network
+    torch.manual_seed(seed)
+    nets = {"sdf_network": SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
+                                      scale=1.0, geometric_init=True, weight_norm=True)}
+    for name in COMP_ORDER:
+        nets[name] = comp_material_network(name)
+    nets["point_light_network"] = PointLightNetwork()
+    nets["point_light_network"].set_light(8.0 * 2.0 * 2.0)
+    return nets
+
+
 def fixture_camera_matrices(width: int, height: int, yaw_deg: float = 0.0):
     """K, W2C (4x4 fp32) of the fixture camera rescaled to width x height, optionally orbited about
     world Y by yaw_deg (C4's 8 views = k*45 degrees)."""

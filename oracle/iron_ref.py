@@ -252,6 +252,202 @@ def ggx_colocated(light, distance: Tensor, normal: Tensor, viewdir: Tensor, para
 
 
 # ----------------------------------------------------------------------------
+# the fork's other co-located BRDF heads -- models/renderer_ggx.py:149-517, 520-858
+# ----------------------------------------------------------------------------
+def fresnel_dielectric(cos_i: Tensor, eta: Tensor) -> Tensor:
+    """renderer_ggx.py:398-416 as its callers use it (cosThetaT argument unused; eta a tensor like cos_i)."""
+    scale = torch.ones_like(cos_i) * eta
+    m = cos_i > 0
+    scale[m] = 1.0 / eta[m]
+    cos_t_sqr = 1 - (1 - cos_i ** 2) * (scale ** 2)
+    cos_i = torch.abs(cos_i)
+    cos_t = torch.sqrt(cos_t_sqr)
+    rs = (cos_i - eta * cos_t) / (cos_i + eta * cos_t)
+    rp = (eta * cos_i - cos_t) / (eta * cos_i + cos_t)
+    return 0.5 * (rs * rs + rp * rp)
+
+
+def fresnel_conductor_exact(cos_i: Tensor, eta, k) -> Tensor:
+    """renderer_ggx.py:419-432 (= CompositeRenderer.fresnel_conductor_exact :592-605); eta, k scalars or tensors."""
+    c2 = cos_i * cos_i
+    s2 = 1 - c2
+    s4 = s2 * s2
+    temp1 = eta * eta - k * k - s2
+    a2pb2 = torch.sqrt(temp1 * temp1 + 4 * k * k * eta * eta)
+    a = torch.sqrt(0.5 * (a2pb2 + temp1))
+    term1 = a2pb2 + c2
+    term2 = 2 * a * cos_i
+    rs2 = (term1 - term2) / (term1 + term2)
+    term3 = a2pb2 * c2 + s4
+    term4 = term2 * s2
+    rp2 = rs2 * (term3 - term4) / (term3 + term4)
+    return 0.5 * (rp2 + rs2)
+
+
+def _coloc_common(light, distance: Tensor, normal: Tensor, viewdir: Tensor):
+    intensity = light / (distance * distance + 1e-10)
+    dot = torch.clamp(torch.sum(viewdir * normal, dim=-1, keepdim=True), min=0.00001, max=0.99999)
+    return intensity, dot
+
+
+def smooth_dielectric(light, distance, normal, viewdir, kd: Tensor, ks: Tensor, alpha=None) -> Dict[str, Tensor]:
+    """SmoothDielectricRenderer.forward, renderer_ggx.py:171-204: constant F = 0.04."""
+    intensity, _ = _coloc_common(light, distance, normal, viewdir)
+    spec = intensity * ks * 0.04
+    diff = intensity * kd * 0.0001
+    return {"diffuse_rgb": diff, "specular_rgb": spec, "rgb": diff + spec}
+
+
+def thin_dielectric(light, distance, normal, viewdir, kd: Tensor, ks: Tensor, alpha=None) -> Dict[str, Tensor]:
+    """ThinDielectricRenderer.forward, renderer_ggx.py:229-267: R = 0.04 with the inter-reflection series."""
+    intensity, _ = _coloc_common(light, distance, normal, viewdir)
+    R = 0.04
+    T = 1 - R
+    if R < 1:
+        R += T * T * R / (1 - R * R)
+    spec = intensity * ks * R
+    diff = intensity * kd * 0.0001
+    return {"diffuse_rgb": diff, "specular_rgb": spec, "rgb": diff + spec}
+
+
+def smooth_conductor(light, distance, normal, viewdir, kd: Tensor, ks: Tensor, alpha=None, eta: float = 2.58,
+                     k: float = 8.21) -> Dict[str, Tensor]:
+    """SmoothConductorCoLocRenderer.forward, renderer_ggx.py:299-319."""
+    intensity, dot = _coloc_common(light, distance, normal, viewdir)
+    spec = intensity * ks * fresnel_conductor_exact(dot, eta, k)
+    diff = intensity * kd * 0.0001
+    return {"diffuse_rgb": diff, "specular_rgb": spec, "rgb": diff + spec}
+
+
+def rough_conductor(light, distance, normal, viewdir, kd: Tensor, ks: Tensor, alpha: Tensor, eta: float = 2.58,
+                    k: float = 8.21) -> Dict[str, Tensor]:
+    """RoughConductorCoLocRenderer.forward, renderer_ggx.py:351-395."""
+    intensity, dot = _coloc_common(light, distance, normal, viewdir)
+    alpha = torch.clamp(alpha, min=0.0001)
+    c2 = dot * dot
+    root = c2 + (1.0 - c2) / (alpha * alpha + 1e-10)
+    D = 1.0 / (np.pi * alpha * alpha * root * root + 1e-10)
+    Fr = fresnel_conductor_exact(dot, eta, k)
+    G = smith_g1(dot, alpha) ** 2
+    spec = intensity * ks * Fr * D * G / (4.0 * dot + 1e-10)
+    diff = intensity * kd * 0.0001
+    return {"diffuse_rgb": diff, "specular_rgb": spec, "rgb": diff + spec}
+
+
+def _diffuse_ggx_tables(intensity: Tensor, cos_theta: Tensor, alpha: Tensor, kd: Tensor, mts_trans: Tensor,
+                        mts_diff_trans: Tensor, eta: float = 1.48958738) -> Tensor:
+    """CompositeRenderer.diffuse_reflection_ggx, renderer_ggx.py:654-681."""
+    alpha = torch.clamp(alpha, min=0.0001)
+    inv_eta2 = 1.0 / (eta * eta)
+    n_theta, n_alpha = 100, 50
+    warped_cos = cos_theta ** 0.25
+    warped_alpha = ((alpha - 0) / (4 - 0)) ** 0.25
+    tx = torch.floor(warped_cos * n_theta).long()
+    ty = torch.floor(warped_alpha * n_alpha).long()
+    t_idx = torch.clamp(ty * n_theta + tx, min=0, max=mts_trans.numel() - 1)
+    T12 = torch.clamp(mts_trans[t_idx.squeeze(-1)].unsqueeze(-1), min=0.0, max=1.0)
+    a_idx = torch.clamp(ty, min=0, max=mts_diff_trans.numel() - 1)
+    Fdr = torch.clamp(1.0 - mts_diff_trans[a_idx.squeeze(-1)].unsqueeze(-1), min=0.0, max=1.0)
+    return intensity * (kd / (1.0 - Fdr + 1e-10) / np.pi) * cos_theta * T12 * T12 * inv_eta2
+
+
+def composite_forward(light, distance: Tensor, normal: Tensor, viewdir: Tensor, params: Dict[str, Tensor],
+                      mts_trans: Tensor, mts_diff_trans: Tensor, use_env_light: bool = False) -> Dict[str, Tensor]:
+    """CompositeRenderer.forward, renderer_ggx.py:781-858, quirks included: the GGX NDF is evaluated with
+    alpha := 1.48958738 (`calc_D_specular(cos, eta)`, :806); the `metallic` / `dielectric` weights are clamped and
+    then unused (the weighted sum :829 is overwritten by the plain sum :831); `rgb` aliases `diffuse_rgb` and is
+    updated in place (:847-853), so the returned "diffuse_rgb" equals "rgb"."""
+    rough = torch.clamp(params["specular_roughness"], min=0.00001)
+    d_eta = torch.clamp(params["dielectric_eta"], min=1.000001, max=1.999999)
+    m_eta = torch.clamp(params["metallic_eta"], min=0.099999, max=4.999999)
+    m_k = torch.clamp(params["metallic_k"], min=0.099999, max=9.999999)
+    ks = torch.clamp(params["specular_albedo"], min=0.00001)
+    kd = torch.clamp(params["diffuse_albedo"], min=0.00001)
+    eta = 1.48958738
+    cos_i = torch.clamp(torch.sum(viewdir * normal, dim=-1, keepdim=True), min=0.00001, max=0.99999)
+    c2 = cos_i * cos_i
+    root = c2 + (1.0 - c2) / (eta * eta + 1e-10)
+    D = 1.0 / (np.pi * eta * eta * root * root + 1e-10)
+    G = smith_g1(cos_i, rough) * smith_g1(cos_i, rough)
+    if use_env_light:
+        intensity = torch.clamp(params["env_light"], min=0.000001, max=20.0)
+    else:
+        intensity = light / (distance * distance + 1e-10)
+    metallic_rgb = ks * fresnel_conductor_exact(cos_i, m_eta, m_k)
+    dielectric_rgb = ks * fresnel_dielectric(cos_i, d_eta) * D * G / (4.0 * torch.abs(cos_i))
+    metallic_rgb = metallic_rgb * intensity
+    dielectric_rgb = dielectric_rgb * intensity
+    specular = dielectric_rgb + metallic_rgb
+    rgb = _diffuse_ggx_tables(intensity, cos_i, rough, kd, mts_trans, mts_diff_trans) + specular
+    ret = {"diffuse_rgb": rgb, "specular_rgb": specular, "metallic_rgb": metallic_rgb, "dielectric_rgb": dielectric_rgb,
+           "rgb": rgb}
+    if use_env_light:
+        ret["env_light"] = intensity
+    return ret
+
+
+def _ns(**kw) -> RenderSpec:
+    return RenderSpec(d_in=6, n_layers=4, multires=6, multires_view=-1, mode="no_view_dir", squeeze_out=False, **kw)
+
+
+# the `comp2` branch of models/network_conf.py:318-447 (render_surface.py asks for 'comp', which the factory as
+# shipped does not define; comp2 is the branch whose keys get_materials_comp consumes)
+COMP_SPECS: Dict[str, RenderSpec] = {
+    "diffuse_albedo_network": RenderSpec(d_in=9, d_out=3, n_layers=4, multires_view=4, mode="idr", squeeze_out=True),
+    "specular_albedo_network": _ns(d_out=3, output_bias=0.0, output_scale=1.0),
+    "specular_roughness_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+    "metallic_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+    "dielectric_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+    "metallic_eta_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+    "metallic_k_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+    "dielectric_eta_network": _ns(d_out=1, output_bias=0.1, output_scale=1.0),
+}
+
+
+def get_materials_comp(nets: Dict[str, Tuple[Dict[str, Tensor], RenderSpec]], points: Tensor, normals: Tensor,
+                       feats: Tensor) -> Dict[str, Tensor]:
+    """models/rendering_func.py:19-49."""
+    def run(name, view):
+        sd, sp = nets[name]
+        return rendering_forward(sd, sp, points, normals, view, feats).abs()
+    return {"diffuse_albedo": run("diffuse_albedo_network", -normals),
+            "specular_albedo": run("specular_albedo_network", None),
+            "metallic": run("metallic_network", None),
+            "dielectric": run("dielectric_network", None),
+            "specular_roughness": run("specular_roughness_network", None),
+            "metallic_eta": run("metallic_eta_network", None),
+            "metallic_k": run("metallic_k_network", None),
+            "dielectric_eta": run("dielectric_eta_network", None)}
+
+
+COMP_RENDER_KEYS = (("color", 3), ("diffuse_color", 3), ("specular_color", 3), ("diffuse_albedo", 3), ("specular_albedo", 3),
+                    ("specular_roughness", 1), ("metallic_eta", 1), ("metallic_k", 1), ("dielectric_eta", 1), ("normal", 3),
+                    ("metallic_rgb", 3), ("metallic", 1), ("dielectric_rgb", 3), ("dielectric", 1))
+
+
+def render_fn_comp(nets, light: float, mts_trans: Tensor, mts_diff_trans: Tensor, interior_mask: Tensor, ray_o: Tensor,
+                   ray_d: Tensor, points: Tensor, normals: Tensor, feats: Tensor) -> Dict[str, Tensor]:
+    """render_surface.py:159-234 with the composite renderer (scalar buffers keep their trailing [.., 1])."""
+    sh = list(interior_mask.shape)
+    out = {k: torch.zeros(sh + [w], dtype=torch.float32) for k, w in COMP_RENDER_KEYS}
+    if interior_mask.any():
+        n = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+        prm = get_materials_comp(nets, points, n, feats)
+        res = composite_forward(torch.tensor(light, dtype=torch.float32), (points - ray_o).norm(dim=-1, keepdim=True), n,
+                                -ray_d, prm, mts_trans, mts_diff_trans)
+        out["color"][interior_mask] = res["rgb"]
+        out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
+        out["specular_color"][interior_mask] = res["specular_rgb"]
+        out["metallic_rgb"][interior_mask] = res["metallic_rgb"]
+        out["dielectric_rgb"][interior_mask] = res["dielectric_rgb"]
+        for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta", "metallic_k", "dielectric_eta",
+                  "metallic", "dielectric"):
+            out[k][interior_mask] = prm[k]
+        out["normal"][interior_mask] = n
+    return out
+
+
+# ----------------------------------------------------------------------------
 # geometry helpers -- models/raytracer.py:223-303
 # ----------------------------------------------------------------------------
 def intersect_sphere(ray_o: Tensor, ray_d: Tensor, r: float = 1.0) -> Tuple[Tensor, Tensor, Tensor]:
@@ -427,6 +623,7 @@ class Scene:
     mts_trans: Tensor
     mts_diff_trans: Tensor
     counter: EvalCounter = field(default_factory=EvalCounter)
+    renderer: str = "ggx"  # "ggx": render_surface.py:117-156; "comp": the composite render_fn, :159-234 (row f-4)
 
     def sdf_fn(self, x: Tensor) -> Tensor:
         self.counter.evals += int(x.shape[0])
@@ -507,7 +704,10 @@ def render_normal_and_color(scene: Scene, results: Dict[str, Tensor], max_num_pt
         else:
             p_h = d_h = o_h = grad = feat = torch.zeros(0, dtype=torch.float32)
         with torch.no_grad():
-            r = render_fn_ggx(scene, m_c, o_h, d_h, p_h, grad, feat)
+            if scene.renderer == "comp":
+                r = render_fn_comp(scene.nets, scene.light, scene.mts_trans, scene.mts_diff_trans, m_c, o_h, d_h, p_h, grad, feat)
+            else:
+                r = render_fn_ggx(scene, m_c, o_h, d_h, p_h, grad, feat)
         for k, v in r.items():
             merged.setdefault(k, []).append(v)
     for k, parts in merged.items():

@@ -168,3 +168,66 @@ def test_closing_and_sobel_restatements_selfcheck():
     ramp = torch.arange(10.0).view(1, 10).expand(6, 10).contiguous() * 0.5
     s = R.sobel_magnitude(ramp)
     assert torch.allclose(s[:, 1:-1], torch.full((6, 8), (0.25 + 1e-6) ** 0.5))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fork's other co-located BRDF heads
+# ---------------------------------------------------------------------------------------------------------------
+def _g9_inputs():
+    g = golden("g9_brdf_heads.npz")
+    prm = {k: t(g[k]) for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic", "dielectric",
+                                "metallic_eta", "metallic_k", "dielectric_eta", "env_light")}
+    return g, prm, torch.tensor(float(g["light"])), t(g["distance"]), t(g["normal"]), t(g["viewdir"])
+
+
+def test_g9_composite_renderer():
+    """CompositeRenderer.forward (renderer_ggx.py:781-858) incl. the env-light branch and the diffuse_rgb == rgb alias."""
+    g, prm, light, dist, nrm, view = _g9_inputs()
+    mt, md = tables()
+    for tag, env in (("comp", False), ("compenv", True)):
+        res = R.composite_forward(light, dist, nrm, view, prm, mt, md, use_env_light=env)
+        keys = ["diffuse_rgb", "specular_rgb", "metallic_rgb", "dielectric_rgb", "rgb"] + (["env_light"] if env else [])
+        assert set(res.keys()) == set(keys)
+        for k in keys:
+            np.testing.assert_allclose(res[k].numpy(), g["%s_%s" % (tag, k)], rtol=2e-6, atol=1e-30, err_msg=tag + k)
+        assert np.array_equal(g[tag + "_diffuse_rgb"], g[tag + "_rgb"])  # the reference's in-place alias
+
+
+def test_g9_simple_heads():
+    g, prm, light, dist, nrm, view = _g9_inputs()
+    kd, ks, a = prm["diffuse_albedo"], prm["specular_albedo"], prm["specular_roughness"]
+    for tag, fn in (("smooth_dielectric", R.smooth_dielectric), ("thin_dielectric", R.thin_dielectric),
+                    ("smooth_conductor", R.smooth_conductor), ("rough_conductor", R.rough_conductor)):
+        res = fn(light, dist, nrm, view, kd, ks, a)
+        for k in ("diffuse_rgb", "specular_rgb", "rgb"):
+            np.testing.assert_allclose(res[k].numpy(), g["%s_%s" % (tag, k)], rtol=2e-6, atol=1e-30, err_msg=tag + k)
+    assert golden_meta()["rough_plastic_reference_error"] == "TypeError"
+
+
+def _comp_scene():
+    nets = scenes.build_comp_networks()
+    mt, md = tables()
+    from _util import cpu_sd
+    rn = {k: (cpu_sd(nets[k]), R.COMP_SPECS[k]) for k in R.COMP_SPECS}
+    return nets, R.Scene(cpu_sd(nets["sdf_network"]), R.SDFSpec(), rn, golden_meta()["light"], mt, md, renderer="comp")
+
+
+def test_g10_comp_materials_and_render():
+    """comp2 constructors reproduce the reference's seeded state; get_materials_comp (rendering_func.py:19-49); and
+    render_camera with the composite render_fn (render_surface.py:159-234) on the C0 crop."""
+    nets, sc = _comp_scene()
+    assert state_hash(nets) == golden_meta()["state_sha256_S2"]
+    g = golden("g10_comp_materials.npz")
+    m = R.get_materials_comp(sc.nets, t(g["points"]), t(g["normals"]), t(g["features"]))
+    assert set(m.keys()) == {"diffuse_albedo", "specular_albedo", "metallic", "dielectric", "specular_roughness",
+                             "metallic_eta", "metallic_k", "dielectric_eta"}
+    for k, v in m.items():
+        np.testing.assert_allclose(v.numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    g = golden("g10_comp_S2_c0.npz")
+    cam = R.CameraSpec(int(g["W"]), int(g["H"]), t(g["K"]), t(g["W2C"]))
+    torch.set_num_threads(8)
+    res = R.render_camera(sc, cam)
+    assert np.array_equal(res["convergent_mask"].numpy(), g["convergent_mask"])
+    for k, w in R.COMP_RENDER_KEYS:
+        assert tuple(res[k].shape) == g[k].shape, k
+        np.testing.assert_allclose(res[k].numpy(), g[k], rtol=3e-5, atol=3e-6, err_msg=k)
