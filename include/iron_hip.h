@@ -124,6 +124,35 @@ int iron_ggx_colocated(float light, const float* distance, const float* normal, 
                        const float* tab_trans, const float* tab_diff_trans, int64_t n, float* diffuse_rgb,
                        float* specular_rgb, float* rgb, void* stream);
 
+/* SURVEY 8 row f-4 -- the fork's other co-located heads.
+ * CompositeRenderer.forward (models/renderer_ggx.py:781-858), quirks included: the GGX NDF is evaluated with
+ * alpha := 1.48958738 (:806), the `metallic` / `dielectric` weight maps are clamped and then unused (:829-831), and
+ * "diffuse_rgb" is the same tensor as "rgb" (in-place alias, :847-853) -- hence no separate diffuse output.  All
+ * parameter maps are raw network outputs (the clamps of :790-797 happen inside); [n,3] albedos, [n] scalars.
+ * env_light != NULL selects use_env_light=True (intensity = clamp(env_light, 1e-6, 20), `distance` unused) and
+ * env_light_out (optional) receives that intensity. */
+typedef struct iron_composite_params {
+    const float* diffuse_albedo;
+    const float* specular_albedo;
+    const float* specular_roughness;
+    const float* metallic_eta;
+    const float* metallic_k;
+    const float* dielectric_eta;
+    const float* env_light; /* NULL: point light */
+} iron_composite_params;
+int iron_composite_colocated(float light, const float* distance, const float* normal, const float* viewdir,
+                             const iron_composite_params* p, const float* tab_trans, const float* tab_diff_trans, int64_t n,
+                             float* specular_rgb, float* metallic_rgb, float* dielectric_rgb, float* rgb,
+                             float* env_light_out, void* stream);
+
+/* kind 0 SmoothDielectricRenderer (:171-204), 1 ThinDielectricRenderer (:229-267), 2 SmoothConductorCoLocRenderer
+ * (:299-319), 3 RoughConductorCoLocRenderer (:351-395); eta, k: the conductor's constants (ignored by kinds 0, 1);
+ * roughness [n] is read by kind 3 only.  (RoughPlasticCoLocRenderer / CoLocRenderer raise TypeError in the reference
+ * -- a float is indexed at :404 -- and have no entry.) */
+int iron_coloc_head(int32_t kind, float light, float eta, float k, const float* distance, const float* normal,
+                    const float* viewdir, const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                    int64_t n, float* diffuse_rgb, float* specular_rgb, float* rgb, void* stream);
+
 /* Image-space passes of raytrace_camera's silhouette handling (models/raytracer.py:554-570), [H,W] fp32:
  * iron_morph_closing3x3 = kornia.morphology.closing(depth, ones(3,3)) (erosion of the dilation, border never wins;
  * `tmp` is an [H,W] scratch image); iron_sobel_magnitude = kornia.filters.sobel(depth) (kernels / 8, replicate

@@ -33,6 +33,11 @@ class iron_net_desc(C.Structure):
                 ("scale", C.c_float)]
 
 
+class iron_composite_params(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta",
+                                          "metallic_k", "dielectric_eta", "env_light")]
+
+
 class iron_trace_params(C.Structure):
     _fields_ = [("sdf_threshold", C.c_float), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
                 ("chunk", C.c_int64)]
@@ -67,6 +72,8 @@ SYMBOLS = {
     "iron_camera_rays": (C.c_int, [C.POINTER(_F), C.POINTER(_F), _P, _I64, _P, _P, _P, _P]),
     "iron_intersect_sphere": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_composite_colocated": (C.c_int, [C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "iron_coloc_head": (C.c_int, [_I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "iron_sobel_magnitude": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "iron_trace_workspace_bytes": (_SZ, [_I64, C.POINTER(iron_trace_params)]),

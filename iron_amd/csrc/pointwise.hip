@@ -70,6 +70,61 @@ __global__ void k_ggx(float light, const float* __restrict__ distance, const flo
     }
 }
 
+struct CompositeArgs {
+    const float *distance, *normal, *viewdir, *kd, *ks, *rough, *m_eta, *m_k, *d_eta, *env_light, *tab_trans, *tab_diff;
+    float *specular, *metallic, *dielectric, *rgb, *env_out;
+    float light;
+    int64_t n;
+};
+
+__global__ void k_composite(CompositeArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const float nn[3] = {a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2]};
+        const float vv[3] = {a.viewdir[3 * i], a.viewdir[3 * i + 1], a.viewdir[3 * i + 2]};
+        const float kd[3] = {a.kd[3 * i], a.kd[3 * i + 1], a.kd[3 * i + 2]};
+        const float ks[3] = {a.ks[3 * i], a.ks[3 * i + 1], a.ks[3 * i + 2]};
+        float intensity;
+        if (a.env_light) {
+            intensity = fminf(fmaxf(a.env_light[i], 0.000001f), 20.0f);
+            if (a.env_out) a.env_out[i] = intensity;
+        } else {
+            const float d = a.distance[i];
+            intensity = a.light / (d * d + 1e-10f);
+        }
+        CompositeOut o;
+        composite_point(intensity, nn, vv, kd, ks, a.rough[i], a.m_eta[i], a.m_k[i], a.d_eta[i], a.tab_trans, a.tab_diff, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (a.specular) a.specular[3 * i + c] = o.specular[c];
+            if (a.metallic) a.metallic[3 * i + c] = o.metallic[c];
+            if (a.dielectric) a.dielectric[3 * i + c] = o.dielectric[c];
+            a.rgb[3 * i + c] = o.rgb[c];
+        }
+    }
+}
+
+__global__ void k_coloc_head(int kind, float light, float eta, float kk, const float* __restrict__ distance,
+                             const float* __restrict__ normal, const float* __restrict__ viewdir, const float* __restrict__ kd,
+                             const float* __restrict__ ks, const float* __restrict__ rough, int64_t n,
+                             float* __restrict__ diffuse_rgb, float* __restrict__ specular_rgb, float* __restrict__ rgb) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float nn[3] = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+        const float vv[3] = {viewdir[3 * i], viewdir[3 * i + 1], viewdir[3 * i + 2]};
+        const float a[3] = {kd[3 * i], kd[3 * i + 1], kd[3 * i + 2]};
+        const float s[3] = {ks[3 * i], ks[3 * i + 1], ks[3 * i + 2]};
+        GgxOut o;
+        coloc_head_point(kind, light, distance[i], nn, vv, a, s, rough ? rough[i] : 0.0f, eta, kk, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (diffuse_rgb) diffuse_rgb[3 * i + c] = o.diffuse[c];
+            if (specular_rgb) specular_rgb[3 * i + c] = o.specular[c];
+            if (rgb) rgb[3 * i + c] = o.rgb[c];
+        }
+    }
+}
+
 // 3x3 max (SIGN=+1) / min (SIGN=-1) filter with a border that never wins: the two passes of kornia's
 // morphology.closing(x, ones(3,3)) with its default 'geodesic' border (models/raytracer.py:554-557).
 template <int SIGN>
@@ -176,6 +231,40 @@ extern "C" int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, fl
     if (n == 0) return IRON_OK;
     if (!depth || !out || depth == out) return IRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_sobel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, depth, H, W, out);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_composite_colocated(float light, const float* distance, const float* normal, const float* viewdir,
+                                        const iron_composite_params* p, const float* tab_trans, const float* tab_diff_trans,
+                                        int64_t n, float* specular_rgb, float* metallic_rgb, float* dielectric_rgb, float* rgb,
+                                        float* env_light_out, void* stream) {
+    if (n < 0 || !p) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!normal || !viewdir || !p->diffuse_albedo || !p->specular_albedo || !p->specular_roughness || !p->metallic_eta ||
+        !p->metallic_k || !p->dielectric_eta || !tab_trans || !tab_diff_trans || !rgb)
+        return IRON_ERR_BAD_ARG;
+    if (!p->env_light && !distance) return IRON_ERR_BAD_ARG;
+    CompositeArgs a;
+    a.distance = distance; a.normal = normal; a.viewdir = viewdir; a.kd = p->diffuse_albedo; a.ks = p->specular_albedo;
+    a.rough = p->specular_roughness; a.m_eta = p->metallic_eta; a.m_k = p->metallic_k; a.d_eta = p->dielectric_eta;
+    a.env_light = p->env_light; a.tab_trans = tab_trans; a.tab_diff = tab_diff_trans; a.specular = specular_rgb;
+    a.metallic = metallic_rgb; a.dielectric = dielectric_rgb; a.rgb = rgb; a.env_out = env_light_out; a.light = light; a.n = n;
+    hipLaunchKernelGGL(k_composite, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, a);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_coloc_head(int32_t kind, float light, float eta, float k, const float* distance, const float* normal,
+                               const float* viewdir, const float* diffuse_albedo, const float* specular_albedo,
+                               const float* roughness, int64_t n, float* diffuse_rgb, float* specular_rgb, float* rgb,
+                               void* stream) {
+    if (n < 0 || kind < 0 || kind > 3) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!distance || !normal || !viewdir || !diffuse_albedo || !specular_albedo) return IRON_ERR_BAD_ARG;
+    if (kind == kHeadRoughConductor && !roughness) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_coloc_head, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, (int)kind, light, eta, k, distance,
+                       normal, viewdir, diffuse_albedo, specular_albedo, roughness, n, diffuse_rgb, specular_rgb, rgb);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

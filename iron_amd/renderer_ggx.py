@@ -1,5 +1,10 @@
-"""GGXColocatedRenderer with the reference's surface (models/renderer_ggx.py:61-146), computed by
-the HIP kernel `iron_ggx_colocated` (csrc/pointwise.hip, csrc/ggx_core.h).
+"""The co-located BRDF heads with the reference's surface (models/renderer_ggx.py), computed by the HIP kernels of
+csrc/pointwise.hip / csrc/ggx_core.h:
+    GGXColocatedRenderer (:61-146)                                   -> iron_ggx_colocated
+    CompositeRenderer.forward (:520-858)           -> iron_composite_colocated
+    SmoothDielectric / ThinDielectric / SmoothConductorCoLoc / RoughConductorCoLoc (:149-395) -> iron_coloc_head
+    RoughPlasticCoLocRenderer, CoLocRenderer (:31-58, 435-517): the reference's forward raises TypeError (a Python
+    float is indexed in fresnel_dielectric, :404); mirrored as such, there is nothing to compute.
 
 The two Mitsuba rough-transmittance tables the reference reads from models/ggx/*.txt ship here as
 iron_amd/data/mts_rtrans_tables.npz (same 5000 + 50 fp32 values).
@@ -62,3 +67,164 @@ class GGXColocatedRenderer(nn.Module):
                                                       out[2].data_ptr(), _lib.stream_ptr(dev)))
         return {"diffuse_rgb": out[0].reshape(sh + [3]), "specular_rgb": out[1].reshape(sh + [3]),
                 "rgb": out[2].reshape(sh + [3])}
+
+
+def _flat(name, x, width, sh):
+    v = _lib.require_cuda_f32(x.detach(), name)
+    if width == 3:
+        return v.expand(sh + [3]).reshape(-1, 3) if v.shape[-1] != 3 else v.reshape(-1, 3)
+    return v.reshape(-1)
+
+
+class CompositeRenderer(nn.Module):
+    """models/renderer_ggx.py:520-858.  The conductor IOR spectra under ./resource/ior that the reference's constructor
+    globs (and only prints) are not part of this package; get_eta / get_K return empty dicts as the reference does
+    when that directory is absent."""
+
+    def __init__(self, use_cuda=False):
+        super().__init__()
+        a, b = load_mts_tables()
+        self.MTS_TRANS, self.MTS_DIFF_TRANS = a, b
+        self.num_theta_samples = 100
+        self.num_alpha_samples = 50
+        self.wavelength = 850
+        self.MATERIAL_ETA, self.MATERIAL_K = {}, {}
+        if use_cuda:
+            self.MTS_TRANS = self.MTS_TRANS.cuda()
+            self.MTS_DIFF_TRANS = self.MTS_DIFF_TRANS.cuda()
+
+    def get_eta(self, wavelength=850):
+        return {}
+
+    def get_K(self, wavelength=850):
+        return {}
+
+    _tables_on = GGXColocatedRenderer._tables_on
+
+    def forward(self, light, distance, normal, viewdir, params={}, use_env_light=False):
+        """params: diffuse_albedo, specular_albedo [...,3]; specular_roughness, metallic_eta, metallic_k, dielectric_eta
+        [...,1] (+ metallic, dielectric, which the reference clamps and never uses; + env_light when use_env_light).
+        Returns diffuse_rgb, specular_rgb, metallic_rgb, dielectric_rgb, rgb (+ env_light); as in the reference,
+        "diffuse_rgb" IS "rgb" (the same tensor: :847-853 add the specular term in place)."""
+        nrm = _lib.require_cuda_f32(normal.detach(), "normal")
+        sh = list(nrm.shape[:-1])
+        nrm = nrm.reshape(-1, 3)
+        n = nrm.shape[0]
+        dev = nrm.device
+        vd = _lib.require_cuda_f32(viewdir.detach(), "viewdir").reshape(-1, 3)
+        for k in ("metallic", "dielectric"):  # read like the reference does (KeyError if absent), then unused
+            params[k]
+        keep = {"kd": _flat("diffuse_albedo", params["diffuse_albedo"], 3, sh), "ks": _flat("specular_albedo", params["specular_albedo"], 3, sh),
+                "rough": _flat("specular_roughness", params["specular_roughness"], 1, sh),
+                "m_eta": _flat("metallic_eta", params["metallic_eta"], 1, sh), "m_k": _flat("metallic_k", params["metallic_k"], 1, sh),
+                "d_eta": _flat("dielectric_eta", params["dielectric_eta"], 1, sh)}
+        p = _lib.iron_composite_params()
+        p.diffuse_albedo, p.specular_albedo, p.specular_roughness = keep["kd"].data_ptr(), keep["ks"].data_ptr(), keep["rough"].data_ptr()
+        p.metallic_eta, p.metallic_k, p.dielectric_eta = keep["m_eta"].data_ptr(), keep["m_k"].data_ptr(), keep["d_eta"].data_ptr()
+        env_out = None
+        dist = None
+        if use_env_light:
+            keep["env"] = _flat("env_light", params["env_light"], 1, sh)
+            p.env_light = keep["env"].data_ptr()
+            env_out = torch.empty(n, dtype=torch.float32, device=dev)
+        else:
+            p.env_light = None
+            dist = _lib.require_cuda_f32(distance.detach(), "distance").reshape(-1)
+        t1, t2 = self._tables_on(dev)
+        spec, met, die, rgb = [torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+        import ctypes as C
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().iron_composite_colocated(float(light), _lib.ptr(dist), nrm.data_ptr(), vd.data_ptr(), C.byref(p),
+                                                            t1.data_ptr(), t2.data_ptr(), n, spec.data_ptr(), met.data_ptr(),
+                                                            die.data_ptr(), rgb.data_ptr(), _lib.ptr(env_out), _lib.stream_ptr(dev)))
+        rgb = rgb.reshape(sh + [3])
+        ret = {"diffuse_rgb": rgb, "specular_rgb": spec.reshape(sh + [3]), "metallic_rgb": met.reshape(sh + [3]),
+               "dielectric_rgb": die.reshape(sh + [3]), "rgb": rgb}
+        if use_env_light:
+            ret["env_light"] = env_out.reshape(sh + [1])
+        return ret
+
+
+class _ColocHead(nn.Module):
+    KIND = -1
+
+    def __init__(self, use_cuda=False):
+        super().__init__()
+        self.eta, self.k = 0.0, 0.0
+
+    def forward(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha=None):
+        nrm = _lib.require_cuda_f32(normal.detach(), "normal")
+        sh = list(nrm.shape[:-1])
+        nrm = nrm.reshape(-1, 3)
+        n = nrm.shape[0]
+        dev = nrm.device
+        dist = _lib.require_cuda_f32(distance.detach(), "distance").reshape(-1)
+        vd = _lib.require_cuda_f32(viewdir.detach(), "viewdir").reshape(-1, 3)
+        kd = _flat("diffuse_albedo", diffuse_albedo, 3, sh)
+        ks = _flat("specular_albedo", specular_albedo, 3, sh)
+        al = _flat("alpha", alpha, 1, sh) if (alpha is not None and self.KIND == 3) else None
+        if self.KIND == 3 and al is None:
+            raise _lib.IronError("RoughConductorCoLocRenderer needs alpha")
+        out = [torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().iron_coloc_head(self.KIND, float(light), float(self.eta), float(self.k), dist.data_ptr(),
+                                                   nrm.data_ptr(), vd.data_ptr(), kd.data_ptr(), ks.data_ptr(), _lib.ptr(al), n,
+                                                   out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _lib.stream_ptr(dev)))
+        return {"diffuse_rgb": out[0].reshape(sh + [3]), "specular_rgb": out[1].reshape(sh + [3]), "rgb": out[2].reshape(sh + [3])}
+
+
+class SmoothDielectricRenderer(_ColocHead):
+    """models/renderer_ggx.py:149-204."""
+    KIND = 0
+
+
+class ThinDielectricRenderer(_ColocHead):
+    """models/renderer_ggx.py:207-267."""
+    KIND = 1
+
+
+class SmoothConductorCoLocRenderer(_ColocHead):
+    """models/renderer_ggx.py:270-319 (ior_path is only globbed by the reference; eta, k are the constants used)."""
+    KIND = 2
+
+    def __init__(self, ior_path=None, eta=2.580000, k=8.210000, use_cuda=False):
+        super().__init__(use_cuda)
+        self.eta, self.k = eta, k
+
+
+class RoughConductorCoLocRenderer(SmoothConductorCoLocRenderer):
+    """models/renderer_ggx.py:322-395."""
+    KIND = 3
+
+
+class RoughPlasticCoLocRenderer(nn.Module):
+    """models/renderer_ggx.py:435-517.  The reference's forward cannot run: it calls fresnel_dielectric(eta=<float>),
+    which evaluates `eta[mask]` (:404) -> TypeError.  Same error here; no output exists to reproduce."""
+
+    def __init__(self, use_cuda=False):
+        super().__init__()
+
+    def forward(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha):
+        raise TypeError("'float' object is not subscriptable (models/renderer_ggx.py:404 via :485: the reference's "
+                        "RoughPlasticCoLocRenderer.forward fails the same way)")
+
+
+class CoLocRenderer(nn.Module):
+    """models/renderer_ggx.py:31-58: material_vector-weighted sum of four heads; its first operand is the rough-plastic
+    head, so the reference's forward raises TypeError before any output exists."""
+
+    def __init__(self, rough_plastic, dielectric, conductor, smooth_conductor, use_cuda=False):
+        super().__init__()
+        self.rough_plastic_renderer = rough_plastic
+        self.dielectric_renderer = dielectric
+        self.rough_conductor_renderer = conductor
+        self.smooth_conductor_renderer = smooth_conductor
+
+    def forward(self, light, distance, normal, viewdir, params={}):
+        kd, ks, alpha = params["diffuse_albedo"], params["specular_albedo"], params["specular_roughness"]
+        mv = params["material_vector"]
+        parts = [r(light, distance, normal, viewdir, kd, ks, alpha) for r in
+                 (self.rough_plastic_renderer, self.dielectric_renderer, self.rough_conductor_renderer, self.smooth_conductor_renderer)]
+        diffuse = sum(mv[..., i:i + 1] * p["diffuse_rgb"] for i, p in enumerate(parts))
+        specular = sum(mv[..., i:i + 1] * p["specular_rgb"] for i, p in enumerate(parts))
+        return {"diffuse_rgb": diffuse, "specular_rgb": specular, "rgb": diffuse + specular, "material_map": mv}

@@ -1,6 +1,8 @@
 """Material query + the stage-2 render_fn, with the reference's surface:
     get_materials            <- models/rendering_func.py:5-16
+    get_materials_comp       <- models/rendering_func.py:19-49
     make_render_fn(renderer) <- the driver's render_fn closure, render_surface.py:117-156
+    make_render_fn_comp(renderer) <- render_fn_comp, render_surface.py:159-234
 
 `make_render_fn` returns a callable with the reference render_fn signature
 (interior_mask, color_network_dict, ray_o, ray_d, points, normals, features) -> dict.  When
@@ -27,6 +29,58 @@ def get_materials(network_dict, points, normals, features, is_metal=False):
     specular_roughness = network_dict["specular_roughness_network"](points, normals, None, features).abs() + 0.01
     return {"diffuse_albedo": diffuse_albedo, "specular_albedo": specular_albedo,
             "specular_roughness": specular_roughness}
+
+
+def get_materials_comp(network_dict, points, normals, features):
+    """models/rendering_func.py:19-49."""
+    def run(name, view):
+        return network_dict[name](points, normals, view, features).abs()
+    return {"diffuse_albedo": run("diffuse_albedo_network", -normals),
+            "specular_albedo": run("specular_albedo_network", None),
+            "metallic": run("metallic_network", None),
+            "dielectric": run("dielectric_network", None),
+            "specular_roughness": run("specular_roughness_network", None),
+            "metallic_eta": run("metallic_eta_network", None),
+            "metallic_k": run("metallic_k_network", None),
+            "dielectric_eta": run("dielectric_eta_network", None)}
+
+
+class CompRenderFn:
+    """render_surface.py:159-234 (render_fn_comp) as a callable: get_materials_comp -> CompositeRenderer -> scatter.
+    Every step runs through its HIP operator (8 material-network launches + one composite kernel); scalar maps keep
+    their trailing [...,1] here and are squeezed by render_normal_and_color like in the reference."""
+
+    _VEC = ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "metallic_rgb", "dielectric_rgb", "normal")
+    _SCALAR = ("specular_roughness", "metallic_eta", "metallic_k", "dielectric_eta", "metallic", "dielectric")
+
+    def __init__(self, renderer):
+        self.renderer = renderer
+
+    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features):
+        dots_sh = list(interior_mask.shape)
+        dev = interior_mask.device
+        rgb = torch.zeros(dots_sh + [3], dtype=torch.float32, device=dev)
+        out = {k: rgb.clone() for k in self._VEC}
+        for k in self._SCALAR:
+            out[k] = rgb[..., 0:1].clone()
+        if interior_mask.any():
+            normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+            params = get_materials_comp(color_network_dict, points, normals, features)
+            light = color_network_dict["point_light_network"]().detach()
+            res = self.renderer(float(light), (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d, params=params)
+            out["color"][interior_mask] = res["rgb"]
+            out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
+            out["specular_color"][interior_mask] = res["specular_rgb"]
+            out["metallic_rgb"][interior_mask] = res["metallic_rgb"]
+            out["dielectric_rgb"][interior_mask] = res["dielectric_rgb"]
+            for k in ("diffuse_albedo", "specular_albedo") + self._SCALAR:
+                out[k][interior_mask] = params[k]
+            out["normal"][interior_mask] = normals
+        return out
+
+
+def make_render_fn_comp(renderer) -> CompRenderFn:
+    return CompRenderFn(renderer)
 
 
 _OUT_KEYS = ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "specular_roughness",
