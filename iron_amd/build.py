@@ -27,8 +27,6 @@ BASE_FLAGS = [
     # the pointwise glue must round like the reference's separate torch mul/add kernels
     "-ffp-contract=off",
     "-Wno-comment", "-Wno-unused-result",
-    # h2 core schedule (mlp_h2.h): fine-grained epilogue, opaque ring position, first fragment reads ahead of the refill
-    "-DIRON_H2_EPI3=1", "-DIRON_H2_OPAQUE_BT=1", "-DIRON_H2_FRAG_FIRST=1",
 ]
 
 # Accumulators of the h2 kernels in VGPRs (no v_accvgpr_read in front of the epilogue, 3-5x less scratch).  The pass

@@ -19,31 +19,7 @@
 #include "iron_common.h"
 #include "mlp_core.h"
 
-// build-time switches (tools/variants.py A/B arms)
-#ifndef IRON_H2_EPI2
-#define IRON_H2_EPI2 0
-#endif
-#ifndef IRON_H2_EPI3
-#define IRON_H2_EPI3 0   // epilogue stages split over the three MFMA gaps of each k-step (implies the EPI2 arithmetic)
-#endif
-#ifndef IRON_H2_OPAQUE_BT
-#define IRON_H2_OPAQUE_BT 0
-#endif
-#ifndef IRON_H2_BUFDMA
-#define IRON_H2_BUFDMA 0
-#endif
-#ifndef IRON_H2_DMA_SPREAD
-#define IRON_H2_DMA_SPREAD 0   // refill instructions issued one per k-step (behind k-steps 1..8) instead of up front
-#endif
-#ifndef IRON_H2_FRAG_FIRST
-#define IRON_H2_FRAG_FIRST 0   // first fragment / bias reads issued BEFORE the refill instructions (their latency hides under them)
-#endif
-#ifndef IRON_H2_DMA_LATE
-#define IRON_H2_DMA_LATE 0
-#endif
-#ifndef IRON_H2_PREFETCH2
-#define IRON_H2_PREFETCH2 0
-#endif
+// build-time switches (tools/variants.py A/B arms; IRON_H2_NO_DMA / IRON_H2_NO_BARRIER are timing experiments only)
 #ifndef IRON_H2_STAMP
 #define IRON_H2_STAMP 0   // diagnostic build: s_memtime stamps of one evaluation's ring steps (tools/stamps.py)
 #endif
@@ -216,9 +192,7 @@ struct Ring {
         // absolute LDS addresses (> 16-bit immediates: one v_add per ds_read, plus AGPR parking of the CSE'd sums).
         // As an opaque scalar the slot base is ONE v_add per step and every fragment read uses an immediate offset.
         int bt = b_take;
-#if IRON_H2_OPAQUE_BT
         asm volatile("" : "+s"(bt));
-#endif
         s.wr = lds + kLdsRing + b_issue * kSlotBytes;
         s.rd = lds + kLdsRing + bt * kSlotBytes;
         off_issue += s.hidden ? (uint32_t)kSlotBytes : 8192u;
@@ -248,14 +222,15 @@ struct Ring {
     }
 };
 
-// this wave's 8 LDS-DMA instructions of one slot: buffer loads with the lane offset in a VGPR and the fragment
-// offset in an SGPR (no 64-bit address arithmetic in the vector pipe)
+// this wave's 8 LDS-DMA instructions of one slot (global_load_lds; the buffer-addressed form measured no faster).
+// The CU's texture-address path moves 64 B/clk, so the 32 KiB of a hidden slot hold all four waves ~500 cycles: a wave
+// does not run ahead of its LDS-DMA instructions (issuing them one by one behind MFMAs, or staggered over the waves,
+// costs 90-170 cycles apiece instead of ~60 in a burst; both measured).
 __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__ wr, bool hidden, int wave) {
 #ifdef IRON_H2_NO_DMA  // timing experiment only: results are garbage
     return;
 #endif
     const int lane = threadIdx.x & 63;
-#if !IRON_H2_BUFDMA
     const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
     if (hidden) {
 #pragma unroll
@@ -273,7 +248,6 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
         }
     }
     return;
-#endif
     if (hidden) {  // 32 fragments of 1 KiB; this wave moves fragments wave, wave+4, ...
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
@@ -289,31 +263,6 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
                                                      lane * 4, (int)(src.off + f * 256), 0, 0);
         }
     }
-}
-
-// instruction i (0..7) of this wave's refill of one slot
-__device__ __forceinline__ void dma_issue_one(const RingSrc& src, char* __restrict__ wr, bool hidden, int wave, int i) {
-#ifdef IRON_H2_NO_DMA
-    return;
-#endif
-    const int lane = threadIdx.x & 63;
-    const int f = wave + 4 * i;
-#if IRON_H2_BUFDMA
-    if (hidden)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 1024), 16,
-                                                 lane * 16, (int)(src.off + f * 1024), 0, 0);
-    else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 256), 4,
-                                                 lane * 4, (int)(src.off + f * 256), 0, 0);
-#else
-    const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
-    if (hidden)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
-                                         (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
-    else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
-                                         (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
-#endif
 }
 
 __device__ __forceinline__ void ring_start(Ring& r, const H2StreamDev& s, char* lds_base, int wave, int lane) {
@@ -366,14 +315,6 @@ __device__ __forceinline__ f32x16 h2_combine(const f32x16& hi, const f32x16& lo)
     return z;
 }
 
-// Scheduling recipe of a ring step (one scheduling region between two s_barriers): LDS fragment reads run one
-// k-step ahead of the MFMAs that consume them, and the VALU epilogue of the PREVIOUS output tile (combine,
-// softplus, fp16 split: ~15 VALU per k-step) is spread between the MFMAs, which execute asynchronously.
-// mask values (LLVM SchedGroupMask): VALU 0x2, MFMA 0x8, DS_READ 0x100.
-#ifndef IRON_H2_VALU_PER_MFMA
-#define IRON_H2_VALU_PER_MFMA 5
-#endif
-
 // One ring step on a head slot: fragments [k-step 0..2][piece hi, lo] (+ padding)
 __device__ __forceinline__ void step_head(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
                                           const RingSrc& src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
@@ -414,20 +355,16 @@ __device__ __forceinline__ float residual_hi(unsigned hpair, float x) {
     return r;
 }
 
-// Empty asm statements that take values as read-write operands: they are chained to the side-effect order (barriers,
-// sched_barrier), so the producing instructions cannot float away from the place in the stream they were written at.
-__device__ __forceinline__ void pin8(float* a) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-__device__ __forceinline__ void pin16(float* a) { pin8(a); pin8(a + 8); }
-
 // epilogue of one output tile: z = hi + lo * 2^-11, activation, split into next-layer B fragments
 template <bool FAST>
 __device__ __forceinline__ void h2_epilogue_split(const f32x16& hi, const f32x16& lo, TileFrag& out) {
     split_tile(softplus_tile<FAST>(h2_combine(hi, lo)), out);
 }
 
-// ---- fine-grained epilogue (IRON_H2_EPI3) ------------------------------------------------------------
+// ---- the staged epilogue -------------------------------------------------------------------------------
+// softplus_100(z) = max(z, 0) + log2(1 + 2^(-|z| * 100 log2 e)) * ln2 / 100: one multiply (source modifiers carry the
+// -|.|), no overflow for any z, no select.  Split: ONE packed conversion per pair for the hi halves, the residual z - hi
+// by v_fma_mix (fp16 source read in place), the 2^11 scale, the second packed conversion.  12 issue slots per element.
 // Pipeline state of one pending output tile.  Stage `ks` of the 16-stage pipeline is cut into three parts, one per
 // MFMA gap of k-step ks, so that no gap carries more than ~6 VALU issue slots (an MFMA leaves 24 of its 32 cycles
 // to the vector issue port; MI355X_MICROARCH.md).
@@ -437,6 +374,8 @@ struct EpiState {
     u32x4 oh[2], ol[2];
 };
 
+// Empty asm statements that take a value as a read-write operand: they are chained to the side-effect order (barriers,
+// sched_barrier), so the producing instruction cannot float away from the place in the stream it was written at.
 __device__ __forceinline__ void pin1(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin1u(unsigned& a) { asm volatile("" : "+v"(a)); }
 
@@ -500,7 +439,6 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
                                             const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
                                             const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev,
                                             unsigned long long* rec = nullptr) {
-#if IRON_H2_FRAG_FIRST
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
     half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -508,171 +446,46 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     __builtin_amdgcn_sched_barrier(0);
     h2_stamp(rec, 1);  // refill issued
     h2_stamp(rec, 7);  // calibration: what a stamp itself costs at this point
-#else
-#if !IRON_H2_DMA_LATE && !IRON_H2_DMA_SPREAD
-    dma_issue(src, wr, src_hidden, wave);
-#endif
-    h2_stamp(rec, 1);  // refill issued
-    if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
-    half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
-#endif
-#if IRON_H2_PREFETCH2
-    half8 gh = lds_frag(rd, 2, lane), gl = lds_frag(rd, 3, lane);  // fragments run TWO k-steps ahead of their MFMAs
-#endif
-    // The previous tile's epilogue runs as a 16-stage software pipeline, one stage per k-step, each stage applied
-    // to all 16 elements of the tile: a stage is 8..16 INDEPENDENT VALU ops (~70-90 issue cycles) placed behind the
-    // k-step's three MFMAs (96 cycles in the matrix pipe), and it consumes what the previous stage produced a whole
-    // k-step earlier, so no dependent VALU chain ever stalls the in-order wave.  sched_barrier(0) keeps hipcc from
-    // re-clustering (left alone it issues the 48 MFMAs first and the ~250 VALU ops afterwards, pipe idle).
-    float z[16], e[16], hb[16], rr[16];
-    f16x2 hp[8];
-    u32x4 oh[2], ol[2];
-#if IRON_H2_EPI3
+    // The previous tile's epilogue runs as a 16-stage software pipeline, one stage per k-step (epi_stage), each stage
+    // cut into three parts that sit in the three MFMA gaps of its k-step; a stage consumes what the previous one
+    // produced a whole k-step earlier, so no dependent VALU chain ever stalls the in-order wave.  sched_barrier(0)
+    // keeps hipcc from re-clustering (left alone it issues the 48 MFMAs first and the ~200 VALU ops afterwards).
+    static_assert(FAST || EPI == 0, "the staged epilogue implements the v_exp/v_log softplus");
     EpiState es;
-#endif
-    constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
-    constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-#if IRON_H2_PREFETCH2
-        half8 nh = gh, nl = gl;
-        if (ks < 14) {
-            nh = lds_frag(rd, 2 * ks + 4, lane);
-            nl = lds_frag(rd, 2 * ks + 5, lane);
-        }
-#else
         half8 nh = fh, nl = fl;
         if (ks < 15) {  // next k-step's fragments: in flight while this step's MFMAs run
             nh = lds_frag(rd, 2 * ks + 2, lane);
             nl = lds_frag(rd, 2 * ks + 3, lane);
         }
-#endif
         const int ti = ks >> 1, s = ks & 1;
-#if IRON_H2_EPI3
         acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
         acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
-#else
-        acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
-        acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
-        acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
-#endif
-#if IRON_H2_DMA_LATE
-        if (ks == 0) dma_issue(src, wr, src_hidden, wave);  // refill issued behind the first k-step's MFMAs
-#endif
-#if IRON_H2_DMA_SPREAD
-        if (ks >= 1 && ks <= kLoadsPerSlot) dma_issue_one(src, wr, src_hidden, wave, ks - 1);
-#endif
-#if IRON_H2_PREFETCH2
-        fh = gh; fl = gl; gh = nh; gl = nl;
-#else
         fh = nh;
         fl = nl;
-#endif
-#if !IRON_H2_EPI3
-        if constexpr (EPI != 0) {
-            static_assert(FAST, "the staged epilogue implements the v_exp/v_log softplus");
-            if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin16(z); }
-#if IRON_H2_EPI2
-            // softplus_100(z) = max(z, 0) + log2(1 + 2^(-|z| * 100 log2 e)) * ln2 / 100: one multiply (source modifiers
-            // carry the -|.|), no overflow for any z, no select
-            if constexpr (ACT == 0) {
-                if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = __builtin_fabsf(z[i]) * -kC1; pin16(e); }
-                if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
-                if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
-                if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
-                if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
-                if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
-                if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = relu_med3(z[i]); pin16(z); }
-                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = __builtin_fmaf(e[i], kC2, z[i]); pin16(z); }
-            } else {
-                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = relu_med3(z[i]); pin16(z); }
-            }
-            if constexpr (EPI == 1) {
-                // hi halves: ONE packed conversion per pair; the residual z - hi comes from v_fma_mix (f16 source read in
-                // place), then the 2^11 scale and the second packed conversion
-                if (ks == 9) {
-                    unsigned hb8[8];
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) hb8[i] = __builtin_bit_cast(unsigned, cvt_pk_rn(z[2 * i], z[2 * i + 1]));
-                    asm volatile("" : "+v"(hb8[0]), "+v"(hb8[1]), "+v"(hb8[2]), "+v"(hb8[3]), "+v"(hb8[4]), "+v"(hb8[5]), "+v"(hb8[6]), "+v"(hb8[7]));
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) hp[i] = __builtin_bit_cast(f16x2, hb8[i]);
-                }
-                if (ks == 10) {
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-                        const unsigned hb = __builtin_bit_cast(unsigned, hp[i]);
-                        rr[2 * i] = residual_lo(hb, z[2 * i]);
-                        rr[2 * i + 1] = residual_hi(hb, z[2 * i + 1]);
-                    }
-                    pin16(rr);
-                }
-                if (ks == 11) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = rr[i] * kLoScale; pin16(rr); }
-                if (ks == 12) {
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-                        const f16x2 lp = cvt_pk_rn(rr[2 * i], rr[2 * i + 1]);
-                        oh[i >> 2][i & 3] = __builtin_bit_cast(unsigned, hp[i]);
-                        ol[i >> 2][i & 3] = __builtin_bit_cast(unsigned, lp);
-                    }
-                }
-            }
-#else
-            if constexpr (ACT == 0) {
-                if (ks == 1) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = z[i] * kC1; pin16(e); }
-                if (ks == 2) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e); }
-                if (ks == 3) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]); pin8(e + 8); }
-                if (ks == 4) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = 1.0f + e[i]; pin16(e); }
-                if (ks == 5) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e); }
-                if (ks == 6) { _Pragma("unroll") for (int i = 8; i < 16; ++i) e[i] = __builtin_amdgcn_logf(e[i]); pin8(e + 8); }
-                if (ks == 7) { _Pragma("unroll") for (int i = 0; i < 16; ++i) e[i] = e[i] * kC2; pin16(e); }
-                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = z[i] > 0.2f ? z[i] : e[i]; pin16(z); }  // 100 z > 20
-            } else {
-                if (ks == 8) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = fmaxf(z[i], 0.0f); pin16(z); }
-            }
-            if constexpr (EPI == 1) {
-                if (ks == 9) {
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { hp[i][0] = (_Float16)z[2 * i]; hp[i][1] = (_Float16)z[2 * i + 1]; }
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { hb[2 * i] = (float)hp[i][0]; hb[2 * i + 1] = (float)hp[i][1]; }
-                    pin16(hb);
-                }
-                if (ks == 10) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = z[i] - hb[i]; pin16(rr); }
-                if (ks == 11) { _Pragma("unroll") for (int i = 0; i < 16; ++i) rr[i] = rr[i] * kLoScale; pin16(rr); }
-                if (ks == 12) {
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-                        f16x2 lp;
-                        lp[0] = (_Float16)rr[2 * i];
-                        lp[1] = (_Float16)rr[2 * i + 1];
-                        oh[i >> 2][i & 3] = __builtin_bit_cast(unsigned, hp[i]);
-                        ol[i >> 2][i & 3] = __builtin_bit_cast(unsigned, lp);
-                    }
-                }
-            }
-#endif
-        }
-#endif  // !IRON_H2_EPI3
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) h2_stamp(rec, 2);
         if (ks == 7) h2_stamp(rec, 3);
         if (ks == 15) h2_stamp(rec, 4);
     }
-#if IRON_H2_EPI3
-    if constexpr (EPI == 1) { oh[0] = es.oh[0]; oh[1] = es.oh[1]; ol[0] = es.ol[0]; ol[1] = es.ol[1]; }
-    if constexpr (EPI == 2) { _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = es.z[i]; }
-#endif
     if constexpr (EPI == 1) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             // pin to this step (LLVM would otherwise sink the epilogue to the end of the layer) and park the finished
             // fragments in the AGPR file
-            asm volatile("" : "+a"(oh[s2]), "+a"(ol[s2]));
-            out_prev.h[s2] = __builtin_bit_cast(half8, oh[s2]);
-            out_prev.l[s2] = __builtin_bit_cast(half8, ol[s2]);
+            asm volatile("" : "+a"(es.oh[s2]), "+a"(es.ol[s2]));
+            out_prev.h[s2] = __builtin_bit_cast(half8, es.oh[s2]);
+            out_prev.l[s2] = __builtin_bit_cast(half8, es.ol[s2]);
         }
     }
     if constexpr (EPI == 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hf_prev[i] = z[i];
+        for (int i = 0; i < 16; ++i) hf_prev[i] = es.z[i];
         asm volatile("" : "+v"(hf_prev));
     }
 }

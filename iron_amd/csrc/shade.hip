@@ -25,19 +25,22 @@ constexpr bool kFastActS = IRON_FAST_SOFTPLUS != 0;
 // grad * e/(e+1) with e = exp(100 z) below the threshold, grad above it.
 template <bool FAST>
 __device__ __forceinline__ void softplus100_both(float z, float& h, float& s) {
-    const float t = z * 100.0f;
-    float e, l;
     if constexpr (FAST) {
-        e = __builtin_amdgcn_exp2f(t * 1.44269504088896340736f);
-        l = __builtin_amdgcn_logf(1.0f + e) * (0.69314718055994530942f * 0.01f);
+        // u = exp(-|100 z|) never overflows: softplus = max(z, 0) + log2(1 + u) ln2 / 100 (mlp_core.h), and
+        // sigmoid(100 z) = (z >= 0 ? 1 : u) / (1 + u) (rounds to exactly 1 above the reference's threshold 100 z = 20)
+        const float u = __builtin_amdgcn_exp2f(__builtin_fabsf(z) * -144.26950408889634f);
+        const float w = 1.0f + u;
+        h = __builtin_fmaf(__builtin_amdgcn_logf(w), 0.0069314718055994531f, fmaxf(z, 0.0f));
+        s = (z >= 0.0f ? 1.0f : u) * __builtin_amdgcn_rcpf(w);
     } else {
-        e = expf(t);
-        l = log1pf(e) / 100.0f;
+        const float t = z * 100.0f;
+        const float e = expf(t);
+        const float l = log1pf(e) / 100.0f;
+        const float sg = e / (e + 1.0f);
+        const bool lin = t > 20.0f;
+        h = lin ? z : l;
+        s = lin ? 1.0f : sg;
     }
-    const float sg = e / (e + 1.0f);
-    const bool lin = t > 20.0f;
-    h = lin ? z : l;
-    s = lin ? 1.0f : sg;
 }
 
 // d(head slots)/d(component c) for one vec3 source with LEVELS (the tangent of head_fill)
