@@ -225,7 +225,6 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m
         split_head(head, hd);
 
         TileFrag in[kHidTiles], out[kHidTiles];
-        f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
         TileFrag dummy_out;
         f32x16 dummy_hf;
         for (int l = 0; l < m.n_hidden_layers; ++l) {
@@ -264,13 +263,18 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m
         if (!is_value) {                                                                                                \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) zt[r] *= sbuf[r * 64 + lane];                                \
         }                                                                                                               \
-        if (last) hf[TO] = zt;                                                                                          \
+        /* the last layer's f32 tile travels in the SAME 16 registers its split fragments would use (hf materialises  */  \
+        /* after the loop): a separate hf[8] live through the runtime layer loop costs 128 VGPRs -> 100+ spilled        */  \
+        if (last) out[TO] = __builtin_bit_cast(TileFrag, zt);                                                           \
         else split_tile(zt, out[TO]);                                                                                   \
     }
             IRON_GTILE(0) IRON_GTILE(1) IRON_GTILE(2) IRON_GTILE(3) IRON_GTILE(4) IRON_GTILE(5) IRON_GTILE(6) IRON_GTILE(7)
 #undef IRON_GTILE
         }
 
+        f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) hf[t] = __builtin_bit_cast(f32x16, out[t]);
         if (is_value) {
             const float s = (row_dot_lds(lds + kLdsRows, hf, half) + m.b_last) / m.scale;
             if (ok && lane < 32 && a.sdf_out) a.sdf_out[li] = s;

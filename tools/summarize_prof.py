@@ -54,8 +54,9 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as f:
         frac = busy / (1024 * cyc) if cyc else 0.0
         w.writerow([k, len(d.get("FETCH_SIZE", d.get("GRBM_GUI_ACTIVE", []))), "%.1f" % fetch, "%.1f" % write, "%.2f" % (hbm / 1e6), "%.4g" % m.get("GRBM_GUI_ACTIVE", 0),
                     "%.3f" % clock, "%.4g" % busy, "%.3f" % frac, "%.4g" % m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0), "%.4g" % m.get("SQ_WAVE_CYCLES", 0), "%.4g" % m.get("SQ_BUSY_CYCLES", 0)])
+        base = k.split("<")[0].strip('"')  # template arguments (backend) and the _h2 suffix name the same bench kernel class
         key = {"k_sphere": "sphere", "k_sampler": "sampler", "k_bisect_a": "bisect_a", "k_bisect_b": "bisect_b", "k_sdf_grad": "sdf_grad",
-               "k_ggx_shade": "ggx"}.get(k, "material" if k.startswith("k_material") else None)
+               "k_sdf_grad_h2": "sdf_grad", "k_ggx_shade": "ggx"}.get(base, "material" if base.startswith("k_material") else None)
         if key and (key != "material" or key not in traffic):
             traffic[key] = {"bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write, "mfma_busy_frac": frac, "eff_clock_ghz": clock,
                             "source": "profiles/%s_pmc_summary.csv" % tag}
