@@ -240,6 +240,44 @@ int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t is_metal, c
                    const uint8_t* conv, int64_t n, const iron_shade_out* out, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* The same with the composite render_fn (render_surface.py:159-234): get_all -> normalise ->
+ * get_materials_comp (models/rendering_func.py:19-49: eight material networks) -> CompositeRenderer.forward.
+ * Scalar maps are [n]; "diffuse_color" receives the same values as "color" (the reference's in-place alias). */
+typedef struct iron_shade_comp_nets {
+    const iron_net_t* sdf;
+    const iron_net_t* diffuse_albedo;
+    const iron_net_t* specular_albedo;
+    const iron_net_t* specular_roughness;
+    const iron_net_t* metallic;
+    const iron_net_t* dielectric;
+    const iron_net_t* metallic_eta;
+    const iron_net_t* metallic_k;
+    const iron_net_t* dielectric_eta;
+} iron_shade_comp_nets;
+
+typedef struct iron_shade_comp_out {
+    float* color;              /* [n,3] */
+    float* diffuse_color;      /* [n,3] == color */
+    float* specular_color;     /* [n,3] */
+    float* diffuse_albedo;     /* [n,3] */
+    float* specular_albedo;    /* [n,3] */
+    float* specular_roughness; /* [n]   */
+    float* metallic_eta;       /* [n]   */
+    float* metallic_k;         /* [n]   */
+    float* dielectric_eta;     /* [n]   */
+    float* normal;             /* [n,3] normalised */
+    float* metallic_rgb;       /* [n,3] */
+    float* metallic;           /* [n]   */
+    float* dielectric_rgb;     /* [n,3] */
+    float* dielectric;         /* [n]   */
+} iron_shade_comp_out;
+
+size_t iron_shade_composite_workspace_bytes(int64_t n);
+
+int iron_shade_composite(const iron_shade_comp_nets* nets, float light, const float* tab_trans, const float* tab_diff_trans,
+                         const float* ray_o, const float* ray_d, const float* points, const uint8_t* conv, int64_t n,
+                         const iron_shade_comp_out* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): per-kernel device time from hipEvents recorded on the
  * caller's stream around each compute kernel.  Off by default.  iron_profile_read blocks on the

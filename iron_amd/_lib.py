@@ -48,6 +48,19 @@ class iron_shade_nets(C.Structure):
                 ("specular_roughness", C.c_void_p)]
 
 
+class iron_shade_comp_nets(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("sdf", "diffuse_albedo", "specular_albedo", "specular_roughness", "metallic", "dielectric",
+                                          "metallic_eta", "metallic_k", "dielectric_eta")]
+
+
+COMP_OUT_FIELDS = ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta",
+                   "metallic_k", "dielectric_eta", "normal", "metallic_rgb", "metallic", "dielectric_rgb", "dielectric")
+
+
+class iron_shade_comp_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in COMP_OUT_FIELDS]
+
+
 class iron_shade_out(C.Structure):
     _fields_ = [("color", C.c_void_p), ("diffuse_color", C.c_void_p), ("specular_color", C.c_void_p),
                 ("diffuse_albedo", C.c_void_p), ("specular_albedo", C.c_void_p),
@@ -84,6 +97,9 @@ SYMBOLS = {
     "iron_profile_enable": (C.c_int, [_I32]),
     "iron_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
     "iron_shade_workspace_bytes": (_SZ, [_I64]),
+    "iron_shade_composite_workspace_bytes": (_SZ, [_I64]),
+    "iron_shade_composite": (C.c_int, [C.POINTER(iron_shade_comp_nets), _F, _P, _P, _P, _P, _P, _P, _I64,
+                                       C.POINTER(iron_shade_comp_out), _P, _SZ, _P]),
     "iron_shade_ggx": (C.c_int, [C.POINTER(iron_shade_nets), _F, _I32, _P, _P, _P, _P, _P, _P, _I64,
                                  C.POINTER(iron_shade_out), _P, _SZ, _P]),
 }

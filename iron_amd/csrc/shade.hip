@@ -568,6 +568,62 @@ __global__ void k_ggx_shade(ShadeArgs a) {
     }
 }
 
+// composite render_fn (render_surface.py:159-234) on the compacted hits: get_materials_comp post-ops (.abs()),
+// CompositeRenderer.forward, scatter to the full-size maps
+struct CompShadeArgs {
+    const int* list;
+    const int* count_ptr;
+    const float *ray_o, *ray_d, *points, *grad;
+    const float* raw[8];  // kd[3], ks[3], roughness, metallic, dielectric, metallic_eta, metallic_k, dielectric_eta
+    const float *tab_trans, *tab_diff;
+    float light;
+    iron_shade_comp_out out;
+};
+
+__global__ void k_composite_shade(CompShadeArgs a) {
+    const int count = *a.count_ptr;
+    const int stride = gridDim.x * blockDim.x;
+    for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < count; li += stride) {
+        const int ray = a.list[li];
+        const float g[3] = {a.grad[3 * (size_t)li], a.grad[3 * (size_t)li + 1], a.grad[3 * (size_t)li + 2]};
+        const float nn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]) + 1e-10f;  // render_surface.py:185
+        const float nrm[3] = {g[0] / nn, g[1] / nn, g[2] / nn};
+        const float p[3] = {a.points[3 * (size_t)ray], a.points[3 * (size_t)ray + 1], a.points[3 * (size_t)ray + 2]};
+        const float o[3] = {a.ray_o[3 * (size_t)ray], a.ray_o[3 * (size_t)ray + 1], a.ray_o[3 * (size_t)ray + 2]};
+        const float v[3] = {-a.ray_d[3 * (size_t)ray], -a.ray_d[3 * (size_t)ray + 1], -a.ray_d[3 * (size_t)ray + 2]};
+        const float e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+        const float dist = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+        float kd[3], ks[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            kd[c] = fabsf(a.raw[0][3 * (size_t)li + c]);
+            ks[c] = fabsf(a.raw[1][3 * (size_t)li + c]);
+        }
+        const float rough = fabsf(a.raw[2][li]), metallic = fabsf(a.raw[3][li]), dielectric = fabsf(a.raw[4][li]);
+        const float m_eta = fabsf(a.raw[5][li]), m_k = fabsf(a.raw[6][li]), d_eta = fabsf(a.raw[7][li]);
+        CompositeOut r;
+        composite_point(a.light / (dist * dist + 1e-10f), nrm, v, kd, ks, rough, m_eta, m_k, d_eta, a.tab_trans, a.tab_diff, r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t q = 3 * (size_t)ray + c;
+            if (a.out.color) a.out.color[q] = r.rgb[c];
+            if (a.out.diffuse_color) a.out.diffuse_color[q] = r.rgb[c];
+            if (a.out.specular_color) a.out.specular_color[q] = r.specular[c];
+            if (a.out.metallic_rgb) a.out.metallic_rgb[q] = r.metallic[c];
+            if (a.out.dielectric_rgb) a.out.dielectric_rgb[q] = r.dielectric[c];
+            if (a.out.diffuse_albedo) a.out.diffuse_albedo[q] = kd[c];
+            if (a.out.specular_albedo) a.out.specular_albedo[q] = ks[c];
+            if (a.out.normal) a.out.normal[q] = nrm[c];
+        }
+        if (a.out.specular_roughness) a.out.specular_roughness[ray] = rough;
+        if (a.out.metallic) a.out.metallic[ray] = metallic;
+        if (a.out.dielectric) a.out.dielectric[ray] = dielectric;
+        if (a.out.metallic_eta) a.out.metallic_eta[ray] = m_eta;
+        if (a.out.metallic_k) a.out.metallic_k[ray] = m_k;
+        if (a.out.dielectric_eta) a.out.dielectric_eta[ray] = d_eta;
+    }
+}
+
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct ShadeLayout {
@@ -703,6 +759,86 @@ extern "C" int iron_render_forward(const iron_net_t* net, const float* points, c
     a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n; a.normalise = 0; a.neg_normal_view = 0;
     a.list_order_aux = 1; a.out = out;
     return launch_material(net, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+}
+
+// composite: the GGX layout followed by the five extra scalar maps
+static size_t comp_extra_off(int64_t n, int i) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    return shade_layout(n).total + (size_t)i * al256(sizeof(float) * nn);
+}
+
+extern "C" size_t iron_shade_composite_workspace_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return comp_extra_off(n, 5);
+}
+
+extern "C" int iron_shade_composite(const iron_shade_comp_nets* nets, float light, const float* tab_trans,
+                                    const float* tab_diff_trans, const float* ray_o, const float* ray_d, const float* points,
+                                    const uint8_t* conv, int64_t n, const iron_shade_comp_out* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!nets || !out) return IRON_ERR_BAD_ARG;
+    const iron_net_t* mats[8] = {nets->diffuse_albedo, nets->specular_albedo, nets->specular_roughness, nets->metallic,
+                                 nets->dielectric, nets->metallic_eta, nets->metallic_k, nets->dielectric_eta};
+    if (!nets->sdf) return IRON_ERR_BAD_ARG;
+    for (int i = 0; i < 8; ++i) {
+        if (!mats[i]) return IRON_ERR_BAD_ARG;
+        if (mats[i]->desc.kind != IRON_NET_RENDER || mats[i]->desc.d_out != (i < 2 ? 3 : 1)) return IRON_ERR_UNSUPPORTED;
+    }
+    if (nets->sdf->desc.kind != IRON_NET_SDF || !nets->sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
+    if (n < 0 || n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!tab_trans || !tab_diff_trans || !ray_o || !ray_d || !points || !conv || !workspace) return IRON_ERR_BAD_ARG;
+    const ShadeLayout L = shade_layout(n);
+    if (workspace_bytes < comp_extra_off(n, 5)) return IRON_ERR_WORKSPACE;
+    if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    int* count = (int*)(base + L.count);
+    int* list = (int*)(base + L.list);
+    float* grad = (float*)(base + L.grad);
+    float* feat = (float*)(base + L.feat);
+    float* raw[8] = {(float*)(base + L.kd), (float*)(base + L.ks), (float*)(base + L.rr), nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 5; ++i) raw[3 + i] = (float*)(base + comp_extra_off(n, i));
+
+    // non-hit pixels are zero in every output (render_surface.py:161-182)
+    IRON_HIP_TRY(hipMemsetAsync(count, 0, 256, st));
+    float* outs3[8] = {out->color, out->diffuse_color, out->specular_color, out->diffuse_albedo, out->specular_albedo, out->normal,
+                       out->metallic_rgb, out->dielectric_rgb};
+    for (float* p : outs3)
+        if (p) IRON_HIP_TRY(hipMemsetAsync(p, 0, sizeof(float) * 3 * (size_t)n, st));
+    float* outs1[6] = {out->specular_roughness, out->metallic_eta, out->metallic_k, out->dielectric_eta, out->metallic, out->dielectric};
+    for (float* p : outs1)
+        if (p) IRON_HIP_TRY(hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, st));
+    {
+        const int64_t b = (n + 255) / 256;
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, st, conv, (int)n, count, list);
+    }
+    const int64_t max_tiles = (n + kTile - 1) / kTile;
+    GradArgs ga;
+    ga.x = points; ga.list = list; ga.count_ptr = count; ga.count = 0;
+    ga.feat_packed = feat; ga.sdf_out = nullptr; ga.grad_out = grad; ga.feat_rows = nullptr;
+    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st);
+    if (rc != IRON_OK) return rc;
+    MatArgs ma;
+    ma.points = points; ma.normals = grad; ma.view = nullptr; ma.feat_rows = nullptr; ma.feat_packed = feat;
+    ma.list = list; ma.count_ptr = count; ma.count = 0; ma.normalise = 1; ma.list_order_aux = 1;
+    for (int i = 0; i < 8; ++i) {
+        ma.neg_normal_view = (i == 0) ? 1 : 0;  // the diffuse head sees view := -normal (rendering_func.py:22)
+        ma.out = raw[i];
+        rc = launch_material(mats[i], ma, max_tiles, st);
+        if (rc != IRON_OK) return rc;
+    }
+    CompShadeArgs sa;
+    sa.list = list; sa.count_ptr = count; sa.ray_o = ray_o; sa.ray_d = ray_d; sa.points = points; sa.grad = grad;
+    for (int i = 0; i < 8; ++i) sa.raw[i] = raw[i];
+    sa.tab_trans = tab_trans; sa.tab_diff = tab_diff_trans; sa.light = light; sa.out = *out;
+    {
+        ProfScope ps(IRON_PROF_GGX, st);
+        const int64_t b = (n + 255) / 256;
+        hipLaunchKernelGGL(k_composite_shade, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, st, sa);
+    }
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
 }
 
 extern "C" size_t iron_shade_workspace_bytes(int64_t n) {

@@ -79,6 +79,37 @@ class CompRenderFn:
         return out
 
 
+    # -- fused path used by render_normal_and_color (same hook name as the GGX render_fn) ------------------------
+    def iron_fused_ggx(self, results: Dict[str, torch.Tensor], sdf_network, color_network_dict) -> Dict[str, torch.Tensor]:
+        pts = _lib.require_cuda_f32(results["points"], "points").reshape(-1, 3)
+        ray_o = _lib.require_cuda_f32(results["ray_o"], "ray_o").reshape(-1, 3)
+        ray_d = _lib.require_cuda_f32(results["ray_d"], "ray_d").reshape(-1, 3)
+        conv = results["convergent_mask"].reshape(-1).contiguous()
+        n = pts.shape[0]
+        dev = pts.device
+        lib = _lib.load()
+        nets = _lib.iron_shade_comp_nets()
+        keep = [sdf_network.hip_net()]
+        nets.sdf = keep[0].handle
+        for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic", "dielectric", "metallic_eta", "metallic_k",
+                  "dielectric_eta"):
+            keep.append(color_network_dict[k + "_network"].hip_net())
+            setattr(nets, k, keep[-1].handle)
+        bufs = {k: torch.empty((n, 3) if k in self._VEC else (n, 1), dtype=torch.float32, device=dev) for k in _lib.COMP_OUT_FIELDS}
+        so = _lib.iron_shade_comp_out()
+        for k in _lib.COMP_OUT_FIELDS:
+            setattr(so, k, bufs[k].data_ptr())
+        t1, t2 = self.renderer._tables_on(dev)
+        ws_bytes = lib.iron_shade_composite_workspace_bytes(n)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        light = float(color_network_dict["point_light_network"]().detach())
+        with torch.cuda.device(dev):
+            _lib.check(lib.iron_shade_composite(C.byref(nets), light, t1.data_ptr(), t2.data_ptr(), ray_o.data_ptr(), ray_d.data_ptr(),
+                                                pts.data_ptr(), conv.data_ptr(), n, C.byref(so), ws.data_ptr(), ws_bytes,
+                                                _lib.stream_ptr(dev)))
+        return bufs
+
+
 def make_render_fn_comp(renderer) -> CompRenderFn:
     return CompRenderFn(renderer)
 

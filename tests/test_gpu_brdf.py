@@ -89,10 +89,14 @@ def test_get_materials_comp(s2):
         assert rel_l2(v.cpu().numpy(), g[k]) <= 1e-5, k
 
 
-def test_render_camera_composite(s2):
+@pytest.mark.parametrize("path", ["fused", "generic"])
+def test_render_camera_composite(s2, path):
+    """fused: one iron_shade_composite launch sequence; generic: the reference's gather / get_all / render_fn flow with
+    every step through its own HIP operator (a plain callable hides the fused hook)."""
     g = golden("g10_comp_S2_c0.npz")
     cam = Camera(int(g["W"]), int(g["H"]), t(g["K"]).cuda(), t(g["W2C"]).cuda())
-    fn = make_render_fn_comp(CompositeRenderer(use_cuda=True))
+    fused_fn = make_render_fn_comp(CompositeRenderer(use_cuda=True))
+    fn = fused_fn if path == "fused" else (lambda *a: fused_fn(*a))
     res = render_camera(cam, s2["sdf_network"], RayTracer(), s2, fn, fill_holes=False, handle_edges=False)
     torch.cuda.synchronize()
     want = {"convergent_mask", "points", "sdf", "distance", "depth", "uv", "ray_o", "ray_d", "ray_d_norm", "color",
