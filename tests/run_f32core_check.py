@@ -1,0 +1,38 @@
+"""Child process of tests/test_gpu_f32core.py: the exact-fp32 MFMA core (IRON_MLP_CORE=f32, selected once per process
+when the library decides its backend) against the reference goldens."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+assert os.environ.get("IRON_MLP_CORE") == "f32"
+
+from iron_amd import scenes  # noqa: E402
+from iron_amd.raytracer import Camera, RayTracer, render_camera  # noqa: E402
+from iron_amd.renderer_ggx import GGXColocatedRenderer  # noqa: E402
+from iron_amd.rendering_func import make_render_fn  # noqa: E402
+from _util import golden, rel_l2, t  # noqa: E402
+
+nets = {k: v.cuda() for k, v in scenes.build_networks("S1").items()}
+g = golden("g2_sdf.npz")
+x = t(g["x"]).cuda()
+y = nets["sdf_network"].sdf(x)[:, 0].cpu().numpy()
+r_sdf = rel_l2(y, g["sdf"])
+_, feat, grad = nets["sdf_network"].get_all(x, is_training=False)
+r_grad = rel_l2(grad.cpu().numpy(), g["getall_grad"])
+assert r_sdf <= 1e-5 and r_grad <= 2e-5, (r_sdf, r_grad)
+
+g = golden("g67_S1_c0.npz")
+cam = Camera(int(g["W"]), int(g["H"]), t(g["K"]).cuda(), t(g["W2C"]).cuda())
+fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=False, handle_edges=False)
+conv = res["convergent_mask"].cpu().numpy()
+flips = int((conv != g["convergent_mask"]).sum())
+both = conv & g["convergent_mask"]
+r_col = rel_l2(res["color"].cpu().numpy()[both], g["color"][both])
+assert flips == 0 and r_col <= 1e-4, (flips, r_col)
+print("F32CORE_CHECK OK sdf %.2e grad %.2e colour %.2e flips %d" % (r_sdf, r_grad, r_col, flips))

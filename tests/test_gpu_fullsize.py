@@ -156,3 +156,40 @@ def test_tracer_edge_cases():
         if both.any():
             tol = 2.5 * kw.get("sdf_threshold", 5e-5) + 1e-4
             assert np.abs(res["distance"].cpu().numpy() - ref["distance"].numpy())[both].max() <= tol, kw
+
+
+def test_fullsize_silhouette_handling_invariants(frame800):
+    """Row f-1 at 800x800 (the oracle needs minutes here): invariants of fill_holes / handle_edges."""
+    nets, cam, fn, plain, _ = frame800
+    from iron_amd.raytracer import morph_closing3x3, sobel_magnitude
+    res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+    torch.cuda.synchronize()
+    H, W = cam.H, cam.W
+    edge, conv = res["edge_mask"], res["convergent_mask"]
+    idx = res["edge_pixel_idx"]
+    n_edge = int(idx.numel())
+    assert n_edge > 500  # a sphere of radius ~0.5 seen at 800^2 has a ~2 000 px silhouette
+    assert not bool((edge & conv).any())                      # raytracer.py:583: convergent_mask &= ~edge_mask
+    assert torch.equal(torch.sort(idx)[0], torch.nonzero(edge.reshape(-1)).reshape(-1))  # one entry per edge pixel
+    assert res["edge_points"].shape == (n_edge, 3) and res["edge_uv"].shape == (n_edge, 2)
+    # every edge pixel holds the projection of its edge point (raytracer.py:481-500)
+    pix = torch.floor(res["edge_uv"]).long()
+    assert torch.equal(pix[:, 1] * W + pix[:, 0], idx)
+    # edge points lie on the surface and at the silhouette: |sdf| small, |n.v| <= 0.05 (+ rounding)
+    sdf, grad = nets["sdf_network"].get_sdf_and_gradient(res["edge_points"])
+    assert float(sdf.abs().max()) <= 5e-3
+    view = cam.get_camera_origin().reshape(1, 3) - res["edge_points"]
+    view = view / view.norm(dim=-1, keepdim=True)
+    dot = ((grad / grad.norm(dim=-1, keepdim=True)) * view).sum(-1)
+    assert float(dot.abs().max()) <= 5e-2 + 1e-4
+    # they sit on the silhouette of the plain render: within 2 px of a depth discontinuity of the hole-filled depth
+    depth = morph_closing3x3(plain["depth"])
+    near_edge = torch.nn.functional.max_pool2d((sobel_magnitude(depth) > 1e-2).float()[None, None], 5, 1, 2)[0, 0] > 0
+    assert float(near_edge.reshape(-1)[idx].float().mean()) >= 0.99
+    # away from the silhouette nothing changed; the edge pixels were re-coloured (blend of an object and a background ray)
+    untouched = ~near_edge
+    assert torch.equal(res["color"][untouched], plain["color"][untouched])
+    assert float((res["color"].reshape(-1, 3)[idx] - plain["color"].reshape(-1, 3)[idx]).abs().max()) > 0
+    # hole filling is idempotent on its own output
+    d2 = morph_closing3x3(depth)
+    assert torch.equal(d2, depth)
