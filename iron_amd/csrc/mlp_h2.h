@@ -433,10 +433,13 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
 // rd / bias / wr are distinct LDS regions (see the note above): __restrict__ is what lets the reads proceed
 // while the refill is in flight.
 // ACT: 0 = softplus(beta=100) (SDF net), 1 = relu (material nets).
-template <bool FAST, int EPI, int ACT = 0>
+// CARRY (with EPI = 1): the pending tile is tile 7 of the PREVIOUS layer, i.e. this layer's own input in[7].  Its
+// fragments leave the pipeline behind k-step 12 and are first multiplied in k-step 14, so the last tile of a layer
+// gets the same hidden epilogue as the other seven instead of an exposed one at the layer boundary.
+template <bool FAST, int EPI, int ACT = 0, bool CARRY = false>
 __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const char* __restrict__ bias, char* __restrict__ wr,
                                             const RingSrc& src, bool src_hidden, int wave, int lane, int tile, bool add_bias,
-                                            const TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
+                                            TileFrag (&in)[kHidTiles], f32x16& acc_hi, f32x16& acc_lo,
                                             const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev,
                                             unsigned long long* rec = nullptr) {
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
@@ -468,12 +471,23 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
         fh = nh;
         fl = nl;
+        if constexpr (CARRY) {
+            static_assert(!CARRY || EPI == 1, "a carried tile ends as split fragments");
+            if (ks == 12) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    asm volatile("" : "+a"(es.oh[s2]), "+a"(es.ol[s2]));
+                    in[kHidTiles - 1].h[s2] = __builtin_bit_cast(half8, es.oh[s2]);
+                    in[kHidTiles - 1].l[s2] = __builtin_bit_cast(half8, es.ol[s2]);
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) h2_stamp(rec, 2);
         if (ks == 7) h2_stamp(rec, 3);
         if (ks == 15) h2_stamp(rec, 4);
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 && !CARRY) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             // pin to this step (LLVM would otherwise sink the epilogue to the end of the layer) and park the finished
@@ -492,10 +506,14 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
 
 // One 256 -> 256 layer on the ring.  HEAD: the layer also has a head product (skip layer); LAST: the result is
 // delivered as f32 tiles in `hf` instead of split fragments in `out`.
-template <bool FAST, bool HEAD, bool LAST, int ACT = 0>
+// CARRY: in[7] is still pending as the accumulators (c_hi, c_lo) the previous layer DEFERred; its epilogue runs under
+// this layer's first tile (step_hidden<CARRY>).  DEFER: this layer's tile 7 is handed on the same way (out[7] is then
+// not written here).
+template <bool FAST, bool HEAD, bool LAST, int ACT = 0, bool CARRY = false, bool DEFER = false>
 __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, const HeadFrag& hd, int lane,
-                                                const TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
-                                                f32x16 (&hf)[kHidTiles]) {
+                                                TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
+                                                f32x16 (&hf)[kHidTiles], f32x16& c_hi, f32x16& c_lo) {
+    static_assert(!(LAST && DEFER), "the last layer ends in f32 tiles");
     const int wave = ring.wave;
     f32x16 acc[2][2];  // [tile parity][hi, lo]: the epilogue of tile t-1 overlaps the MFMAs of tile t
     TileFrag dummy_out;
@@ -512,7 +530,10 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
         }                                                                                                                  \
         ring.sync();                                                                                                       \
         const RingStep st = ring.step();                                                                                   \
-        if constexpr ((TO) == 0)                                                                                           \
+        if constexpr ((TO) == 0 && CARRY)                                                                                  \
+            step_hidden<FAST, 1, ACT, true>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0],   \
+                                            acc[P][1], c_hi, c_lo, dummy_out, dummy_hf, st.rec);                           \
+        else if constexpr ((TO) == 0)                                                                                      \
             step_hidden<FAST, 0, ACT>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, !HEAD, in, acc[P][0], acc[P][1],   \
                                  acc[Q][0], acc[Q][1], dummy_out, dummy_hf, st.rec);                                       \
         else if constexpr (LAST)                                                                                           \
@@ -525,7 +546,10 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
     IRON_H2_TILE(0) IRON_H2_TILE(1) IRON_H2_TILE(2) IRON_H2_TILE(3)
     IRON_H2_TILE(4) IRON_H2_TILE(5) IRON_H2_TILE(6) IRON_H2_TILE(7)
 #undef IRON_H2_TILE
-    if constexpr (ACT == 0) {
+    if constexpr (DEFER) {
+        c_hi = acc[1][0];
+        c_lo = acc[1][1];
+    } else if constexpr (ACT == 0) {
         if constexpr (LAST) hf[kHidTiles - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
         else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[kHidTiles - 1]);
     } else {
@@ -548,7 +572,10 @@ __device__ __forceinline__ float row_dot_lds(const char* __restrict__ row, const
 
 // SDFNetwork hidden stack on the h2 core.  All four waves of the workgroup must call it together.
 // On return hf (f32 tiles) holds the last hidden activation.
-template <bool FAST>
+// DEFER_TILES: hand every layer's last tile to the next layer's first step (see h2_hidden_layer); false keeps the
+// exposed epilogue at the layer boundary (an escape hatch: hipcc 7.2's vgpr-form MFMA pass has crashed on k_sampler
+// with the deferral in one revision of this file).
+template <bool FAST, bool DEFER_TILES = true>
 __device__ __forceinline__ void sdf_hidden_stack_h2(Ring& ring, const char* lds, int n_hidden_layers, int skip_layer,
                                                     float scale, float x, float y, float z, int lane,
                                                     f32x16 (&hf)[kHidTiles]) {
@@ -561,7 +588,10 @@ __device__ __forceinline__ void sdf_hidden_stack_h2(Ring& ring, const char* lds,
     HeadFrag hd;
     split_head(pe, hd);
 
-    TileFrag in[kHidTiles], out[kHidTiles];
+    // Two activation sets X, Y alternate as input and output (no 128-register copy at a layer boundary: a copying layer
+    // loop costs ~280 register moves per layer).  The launchers admit n_hidden_layers = 8, skip_layer = 4 only: an even
+    // number of middle layers, the skip layer second in its pair.
+    TileFrag X[kHidTiles], Y[kHidTiles];
     // layer 0: head only (9 MFMAs per tile: epilogue in place)
 #pragma unroll
     for (int to = 0; to < kHidTiles; ++to) {
@@ -569,16 +599,20 @@ __device__ __forceinline__ void sdf_hidden_stack_h2(Ring& ring, const char* lds,
         const RingStep st = ring.step();
         f32x16 a_hi = zero16(), a_lo = zero16();
         step_head(st.rd, lds + kLdsBias, st.wr, st.src, st.hidden, wave, lane, to, true, hd, a_hi, a_lo);
-        h2_epilogue_split<FAST>(a_hi, a_lo, out[to]);
+        h2_epilogue_split<FAST>(a_hi, a_lo, X[to]);
     }
-    for (int l = 1; l < n_hidden_layers; ++l) {
-#pragma unroll
-        for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
-        const char* bias = lds + kLdsBias + l * 1024;
-        if (l == n_hidden_layers - 1) h2_hidden_layer<FAST, false, true>(ring, bias, hd, lane, in, out, hf);
-        else if (l == skip_layer) h2_hidden_layer<FAST, true, false>(ring, bias, hd, lane, in, out, hf);
-        else h2_hidden_layer<FAST, false, false>(ring, bias, hd, lane, in, out, hf);
+    // layers (1,2), (3,4), (5,6): X -> Y -> X; every layer but the last may defer its tile 7 (DEFER_TILES)
+    f32x16 c_hi, c_lo;
+    constexpr bool D = DEFER_TILES;
+    for (int l = 1; l + 1 < n_hidden_layers - 1; l += 2) {
+        const char* bias_a = lds + kLdsBias + l * 1024;
+        const char* bias_b = bias_a + 1024;
+        if (l == 1) h2_hidden_layer<FAST, false, false, 0, false, D>(ring, bias_a, hd, lane, X, Y, hf, c_hi, c_lo);
+        else h2_hidden_layer<FAST, false, false, 0, D, D>(ring, bias_a, hd, lane, X, Y, hf, c_hi, c_lo);
+        if (l + 1 == skip_layer) h2_hidden_layer<FAST, true, false, 0, D, D>(ring, bias_b, hd, lane, Y, X, hf, c_hi, c_lo);
+        else h2_hidden_layer<FAST, false, false, 0, D, D>(ring, bias_b, hd, lane, Y, X, hf, c_hi, c_lo);
     }
+    h2_hidden_layer<FAST, false, true, 0, D, false>(ring, lds + kLdsBias + (n_hidden_layers - 1) * 1024, hd, lane, X, Y, hf, c_hi, c_lo);
 }
 
 }  // namespace iron

@@ -478,14 +478,16 @@ __global__ __launch_bounds__(256, 1) void k_material_h2(H2StreamDev hs, RenderNe
                 split_tile(v, out[t]);
             }
         }
-        for (int l = 0; l < net.n_hidden_layers; ++l) {
-#pragma unroll
-            for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
-            const char* bias = lds + kLdsBias + l * 1024;
-            if (l == net.n_hidden_layers - 1) h2_hidden_layer<true, false, true, 1>(ring, bias, hd, lane, in, out, hf);
-            else if (l == 0) h2_hidden_layer<true, true, false, 1>(ring, bias, hd, lane, in, out, hf);
-            else h2_hidden_layer<true, false, false, 1>(ring, bias, hd, lane, in, out, hf);
+        // `out` holds the features; the two sets then alternate as layer input / output (no copies; the launcher admits an
+        // even layer count): l0 (features + head) out -> in, middle pairs in -> out -> in, last layer in -> hf
+        f32x16 c_hi, c_lo;
+        h2_hidden_layer<true, true, false, 1, false, true>(ring, lds + kLdsBias, hd, lane, out, in, hf, c_hi, c_lo);
+        for (int l = 1; l + 1 < net.n_hidden_layers - 1; l += 2) {
+            h2_hidden_layer<true, false, false, 1, true, true>(ring, lds + kLdsBias + l * 1024, hd, lane, in, out, hf, c_hi, c_lo);
+            h2_hidden_layer<true, false, false, 1, true, true>(ring, lds + kLdsBias + (l + 1) * 1024, hd, lane, out, in, hf, c_hi, c_lo);
         }
+        h2_hidden_layer<true, false, true, 1, true, false>(ring, lds + kLdsBias + (net.n_hidden_layers - 1) * 1024, hd, lane, in, out, hf,
+                                                           c_hi, c_lo);
         for (int c = 0; c < net.d_out; ++c) {
             float v = row_dot_lds(lds + kLdsRows + c * 1024, hf, half) + net.b_last[c];
             v = net.output_scale * (v + net.output_bias);  // fields.py:235
@@ -697,7 +699,7 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
     const int lp = d.multires > 0 ? d.multires : 0;
     const int lv = d.multires_view > 0 ? d.multires_view : 0;
     ProfScope ps(IRON_PROF_MATERIAL, st);
-    if (use_h2_core() && net->h2_blob && r.n_hidden_layers >= 2) {
+    if (use_h2_core() && net->h2_blob && r.n_hidden_layers >= 2 && r.n_hidden_layers % 2 == 0) {
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)k_material_h2<0, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);

@@ -96,7 +96,8 @@ struct BackendF32 {
     __device__ __forceinline__ void finish() {}
 };
 
-struct BackendH2 {
+template <bool DEFER_TILES>
+struct BackendH2T {
     static constexpr int kThreads = 256;
     Ring ring;
     char* lds;
@@ -121,11 +122,20 @@ struct BackendH2 {
     }
     __device__ __forceinline__ float eval(float x, float y, float z) {
         f32x16 hf[kHidTiles];
-        sdf_hidden_stack_h2<kFastActT>(ring, lds, m.n_hidden_layers, m.skip_layer, m.scale, x, y, z, lane, hf);
+        sdf_hidden_stack_h2<kFastActT, DEFER_TILES>(ring, lds, m.n_hidden_layers, m.skip_layer, m.scale, x, y, z, lane, hf);
         return (row_dot_lds(lds + kLdsRows, hf, lane >> 5) + m.b_last) / m.scale;
     }
     __device__ __forceinline__ void finish() { ring.drain(); }
 };
+
+#ifndef IRON_TRACE_DEFER
+#define IRON_TRACE_DEFER 1
+#endif
+typedef BackendH2T<IRON_TRACE_DEFER != 0> BackendH2;
+#ifndef IRON_SAMPLER_DEFER
+#define IRON_SAMPLER_DEFER 1  // see sdf_hidden_stack_h2 (0: the fallback if hipcc's vgpr-form pass crashes on k_sampler again)
+#endif
+typedef BackendH2T<IRON_SAMPLER_DEFER != 0> BackendH2Sampler;
 
 #define IRON_TRACE_KERNEL_ARGS SdfNetDev net, H2StreamDev hs, H2Meta hm, TraceArgs a, TraceWs w
 
@@ -499,7 +509,7 @@ static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const T
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)k_sphere<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
-            (void)hipFuncSetAttribute((const void*)k_sampler<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_sampler<BackendH2Sampler>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
             (void)hipFuncSetAttribute((const void*)k_bisect_a<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
             (void)hipFuncSetAttribute((const void*)k_bisect_b<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
             attr = true;
@@ -509,7 +519,7 @@ static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const T
         const dim3 grid((unsigned)(wgs < cus ? wgs : cus)), block(256);
         switch (which) {
             case 0: hipLaunchKernelGGL(k_sphere<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
-            case 1: hipLaunchKernelGGL(k_sampler<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 1: hipLaunchKernelGGL(k_sampler<BackendH2Sampler>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
             case 2: hipLaunchKernelGGL(k_bisect_a<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
             default: hipLaunchKernelGGL(k_bisect_b<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
         }
