@@ -13,6 +13,13 @@ struct H2Meta {
 
 bool use_h2_core();
 
+// The SDF stack on the h2 core (sdf_hidden_stack_h2) is written for the reference's 8 x 256 network with the skip at
+// layer 4 (models/network_conf.py:31-44) and needs the h2 stream (absent when a folded weight overflows fp16); any
+// other SDF network runs on the exact-fp32 core.
+inline bool h2_sdf_usable(const iron_net* net) {
+    return use_h2_core() && net->h2_blob && net->sdf.n_hidden_layers == 8 && net->sdf.skip_layer == 4;
+}
+
 // biases / output rows -> LDS, then start the weight ring.  Called once per kernel by all 256 threads.
 __device__ __forceinline__ void h2_setup(const H2StreamDev& s, char* lds, Ring& ring) {
     const int tid = threadIdx.x;

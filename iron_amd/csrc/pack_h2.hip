@@ -10,7 +10,12 @@ namespace iron {
 // element j of lane (i, h) in the fragment of k-step ks (input tile ti = ks>>1, sub-step s = ks&1) multiplies
 // input feature 32*ti + 16*s + 8*(j>>2) + 4*h + (j&3): the order in which the previous layer's accumulator
 // registers 8s..8s+7 are handed over as the B operand.
+// set when a folded weight does not fit fp16 (|w| >= 65504, or not finite): the net then keeps only its fp32 pack and
+// every kernel runs it on the exact-fp32 core
+__device__ int g_h2_weight_overflow;
+
 __device__ __forceinline__ void store_split(_Float16* dst_hi, _Float16* dst_lo, float w) {
+    if (!(fabsf(w) < 65504.0f)) atomicOr(&g_h2_weight_overflow, 1);
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)((w - (float)hi) * kLoScale);
     *dst_hi = hi;
@@ -59,6 +64,23 @@ using namespace iron;
 
 namespace iron {
 
+static int h2_overflow_reset(hipStream_t st) {
+    const int zero = 0;
+    IRON_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_h2_weight_overflow), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st));
+    return IRON_OK;
+}
+
+// after the pack kernels have run (stream synchronised): drop the h2 stream if a weight overflowed fp16
+static int h2_overflow_check(iron_net* net) {
+    int flag = 0;
+    IRON_HIP_TRY(hipMemcpyFromSymbol(&flag, HIP_SYMBOL(g_h2_weight_overflow), sizeof(int), 0, hipMemcpyDeviceToHost));
+    if (flag) {
+        (void)hipFree(net->h2_blob);
+        net->h2_blob = nullptr;
+    }
+    return IRON_OK;
+}
+
 // Builds the h2 stream of an SDF network next to its fp32 pack.  Slot sequence (= memory order):
 //   layer 0: 8 head slots; layers 1..n-2: per output tile [head slot if skip layer] hidden slot;
 //   then (full stream only) the 8 hidden slots of the feature rows of the last layer.
@@ -86,6 +108,7 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     const size_t total = rows_off + kLdsRowsBytes + 65536;  // tail padding: the ring may prefetch past the end
     IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
     IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
+    { const int rc0 = h2_overflow_reset(st); if (rc0 != IRON_OK) return rc0; }
     char* base = (char*)net->h2_blob;
     IRON_HIP_TRY(hipMemcpyAsync(base + table_off, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     IRON_HIP_TRY(hipStreamSynchronize(st));  // `table` is host memory going out of scope
@@ -134,7 +157,7 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     net->h2_trace = s;
     s.n_slots = n_full;
     net->h2_full = s;
-    return IRON_OK;
+    return h2_overflow_check(net);
 }
 
 // h2 stream of a material network.  Sequence: layer 0: per output tile [head slot][hidden slot = feature part];
@@ -157,6 +180,7 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
     const size_t total = rows_off + kLdsRowsBytes + 65536;
     IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
     IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
+    { const int rc0 = h2_overflow_reset(st); if (rc0 != IRON_OK) return rc0; }
     char* base = (char*)net->h2_blob;
     size_t q = 0;
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
@@ -184,7 +208,7 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
         if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
     net->h2_trace = s;
     net->h2_full = s;
-    return IRON_OK;
+    return h2_overflow_check(net);
 }
 
 }  // namespace iron

@@ -1,6 +1,7 @@
 // Batched SDF queries: SDFNetwork.forward / .sdf (models/fields.py:82-104).
 // This is the pure "8x256 SDF MLP" kernel the MFMA roofline sub-target is measured on.
 #include "mlp_core.h"
+#include "h2_setup.h"
 
 namespace iron {
 
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(64, 1) void k_sdf_full(SdfNetDev net, const float* 
 }  // namespace iron
 
 namespace iron {
-bool use_h2_core();
 int launch_sdf_values_h2(const iron_net* net, const float* x, int64_t n, float* out, hipStream_t st);
 }
 
@@ -82,7 +82,7 @@ extern "C" int iron_sdf_forward(const iron_net_t* net, const float* x, int64_t n
     const int64_t n_tiles = (n + kTile - 1) / kTile;
     if (((uintptr_t)x & 3) || ((uintptr_t)out & 3)) return IRON_ERR_BAD_ARG;
     ProfScope ps(IRON_PROF_SDF_FORWARD, st);
-    if (out_cols == 1 && use_h2_core() && net->h2_blob) return launch_sdf_values_h2(net, x, n, out, st);
+    if (out_cols == 1 && h2_sdf_usable(net)) return launch_sdf_values_h2(net, x, n, out, st);
     if (out_cols == 1) {
         hipLaunchKernelGGL(k_sdf_values, dim3(grid_for_tiles(n_tiles)), dim3(64), 0, st, net->sdf, x, n, out, 1);
     } else {

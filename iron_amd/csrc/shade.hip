@@ -658,7 +658,7 @@ static int cu_count() {
 }
 
 static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st) {
-    if (use_h2_core() && sdf->h2_blob && sdf->sdf.n_hidden_layers == 8 && sdf->sdf.skip_layer == 4) {
+    if (h2_sdf_usable(sdf)) {
         static bool attr2 = false;
         if (!attr2) {
             IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_sdf_grad_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsGradTotal));

@@ -584,7 +584,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     a.lin = lin_steps; a.conv = conv; a.points = points; a.sdf = sdf_out; a.dist = dist;
     a.n = (int)n; a.n_steps = p->n_steps; a.iters = p->sphere_tracing_iters; a.thr = p->sdf_threshold;
     a.chunk = p->chunk > 0 ? p->chunk : 0;
-    const bool h2 = use_h2_core() && sdf->h2_blob && sdf->sdf.n_hidden_layers == 8 && sdf->sdf.skip_layer == 4;
+    const bool h2 = h2_sdf_usable(sdf);
     if (phase == 0) {
         IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, align256(sizeof(TraceCounters)), st));
         if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));

@@ -80,3 +80,21 @@ def test_ggx_golden():
     bad = np.abs(diff - g["diffuse_rgb"]) > 2e-5 * np.abs(g["diffuse_rgb"]) + 1e-30
     flips = int(bad.any(axis=-1).sum())
     assert flips <= max(2, diff.shape[0] // 500), "table-bin flips: %d of %d" % (flips, diff.shape[0])
+
+
+def test_fp16_overflowing_weight_selects_the_fp32_core():
+    """A folded weight beyond fp16's range cannot be split for the h2 core: the library keeps only the fp32 pack for that
+    network and every kernel runs it on the exact-fp32 MFMA core (never a CPU path) -- results stay at parity."""
+    from oracle import iron_ref as R
+    from _util import cpu_sd
+    nets = scenes.build_networks("S1")
+    sdf = nets["sdf_network"]
+    with torch.no_grad():
+        sdf.lin3.weight_g[7] *= 3.0e5   # row norm g scales the whole folded row: |w| ~ 1e4..1e5 > 65504 for some entries
+    assert float((sdf.lin3.weight_g[7] * sdf.lin3.weight_v[7] / sdf.lin3.weight_v[7].norm()).detach().abs().max()) > 65504.0
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(300, 3, generator=g) * 2 - 1
+    ref = R.sdf_forward(cpu_sd(sdf), R.SDFSpec(), x)[:, 0].numpy()
+    y = sdf.cuda().sdf(x.cuda())[:, 0].cpu().numpy()
+    assert np.all(np.isfinite(y))
+    assert rel_l2(y, ref) <= 1e-5
