@@ -704,6 +704,7 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)k_material_h2<0, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
             (void)hipFuncSetAttribute((const void*)k_material_h2<6, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_material_h2<6, 0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
             attr3 = true;
         }
         const int64_t groups = (max_tiles + 3) / 4;
@@ -713,6 +714,8 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
             hipLaunchKernelGGL((k_material_h2<0, 4, true, true>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a);
         } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
             hipLaunchKernelGGL((k_material_h2<6, 0, false, true>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a);
+        } else if (d.mode == IRON_MODE_POINTS_ONLY && lp == 6) {  // comp2's env_light_network (network_conf.py:367-378)
+            hipLaunchKernelGGL((k_material_h2<6, 0, false, false>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a);
         } else {
             return IRON_ERR_UNSUPPORTED;
         }
@@ -723,6 +726,8 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
         hipLaunchKernelGGL((k_material<0, 4, true, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
         hipLaunchKernelGGL((k_material<6, 0, false, true>), dim3(grid), dim3(64), 0, st, r, a);
+    } else if (d.mode == IRON_MODE_POINTS_ONLY && lp == 6) {
+        hipLaunchKernelGGL((k_material<6, 0, false, false>), dim3(grid), dim3(64), 0, st, r, a);
     } else {
         return IRON_ERR_UNSUPPORTED;
     }

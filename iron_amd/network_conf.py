@@ -49,12 +49,19 @@ def comp_material_network(name: str) -> RenderingNetwork:
                             mode="no_view_dir", squeeze_out=False, output_bias=bias, output_scale=1.0)
 
 
+def comp_env_light_network() -> RenderingNetwork:
+    """comp2's env_light_network (models/network_conf.py:367-378): a points_only PE-6 head with one output."""
+    return RenderingNetwork(d_in=3, d_out=1, d_feature=256, d_hidden=256, n_layers=4, multires=6, multires_view=-1,
+                            mode="points_only", squeeze_out=False, output_bias=0.0, output_scale=1.0)
+
+
 def init_rendering_network_dict(renderer_name="ggx", device="cuda"):
     """models/network_conf.py:47-122 (`ggx`) and :318-447 (`comp2`; `comp`, which render_surface.py:107 asks for, is not
-    defined by the reference's factory and is served by the same shapes).  color_network / env_light_network of the
-    comp2 dict are not consumed by the render path and are not built."""
+    defined by the reference's factory and is served by the same shapes).  color_network of the comp2 dict (the
+    stage-1 colour net, unused by the render path) is not built."""
     if renderer_name in ("comp", "comp2"):
         d = {name: comp_material_network(name).to(device) for name in COMP_NETWORKS}
+        d["env_light_network"] = comp_env_light_network().to(device)
         d["point_light_network"] = PointLightNetwork().to(device)
         return d
     if renderer_name != "ggx":

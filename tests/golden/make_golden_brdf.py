@@ -4,7 +4,8 @@ Same rules as make_golden.py (whose helpers it reuses): the real reference is im
 and only the resulting data is written.  G9 = the pointwise heads of models/renderer_ggx.py (CompositeRenderer.forward
 with and without env light, SmoothDielectric / ThinDielectric / SmoothConductorCoLoc / RoughConductorCoLoc);
 G10 = get_materials_comp (models/rendering_func.py:19-49) and render_camera with the composite render_fn of
-render_surface.py:159-234 on scene S2 (S0's SDF + the `comp2` material networks of models/network_conf.py:318-447).
+render_surface.py:159-234 on scene S2 (S0's SDF + the `comp2` material networks of models/network_conf.py:318-447);
+G11 = the forward of a points_only RenderingNetwork (comp2's env_light_network).
 
 RoughPlasticCoLocRenderer / CoLocRenderer are NOT recorded: the reference's RoughPlasticCoLocRenderer.forward passes a
 Python float as `eta` to fresnel_dielectric, which indexes it (renderer_ggx.py:404,485) -> TypeError; there is no
@@ -153,8 +154,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g10_comp_S2_c0.npz"), K=npf(cam.K), W2C=npf(cam.W2C), W=np.int64(cam.W), H=np.int64(cam.H),
                         **{k: npf(v) for k, v in res.items()})
     meta["n_conv_S2_c0"] = int(res["convergent_mask"].sum())
+
+    # ---- G11: a points_only material head (comp2's env_light_network, models/network_conf.py:367-378), seed 7
+    torch.manual_seed(7)
+    env = RenderingNetwork(d_in=3, d_out=1, d_feature=256, d_hidden=256, n_layers=4, multires=6, multires_view=-1,
+                           mode="points_only", squeeze_out=False, output_bias=0.0, output_scale=1.0)
+    with torch.no_grad():
+        env_out = env(pts, None, None, feat)
+    meta["state_sha256_env_light"] = MG.state_hash({"env_light_network": env})
+    np.savez_compressed(os.path.join(HERE, "g11_points_only.npz"), points=npf(pts), features=npf(feat), out=npf(env_out))
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
-    print({k: meta[k] for k in ("state_sha256_S2", "rough_plastic_reference_error", "n_conv_S2_c0")})
+    print({k: meta[k] for k in ("state_sha256_S2", "state_sha256_env_light", "rough_plastic_reference_error", "n_conv_S2_c0")})
 
 
 if __name__ == "__main__":

@@ -115,3 +115,14 @@ def test_render_camera_composite(s2, path):
         r = float(np.linalg.norm(a - b) / max(scale, 1e-30))
         print("%-20s rel-L2 %.2e" % (k, r))
         assert r <= 1e-4, (k, r)
+
+
+def test_points_only_head():
+    """A points_only material network (comp2's env_light_network) on both MLP cores' dispatch (h2 by default)."""
+    from iron_amd.network_conf import comp_env_light_network
+    torch.manual_seed(7)
+    env = comp_env_light_network().cuda()
+    g = golden("g11_points_only.npz")
+    out = env(t(g["points"]).cuda(), None, None, t(g["features"]).cuda())
+    assert tuple(out.shape) == g["out"].shape
+    assert rel_l2(out.cpu().numpy(), g["out"]) <= 1e-5

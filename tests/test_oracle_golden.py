@@ -231,3 +231,16 @@ def test_g10_comp_materials_and_render():
     for k, w in R.COMP_RENDER_KEYS:
         assert tuple(res[k].shape) == g[k].shape, k
         np.testing.assert_allclose(res[k].numpy(), g[k], rtol=3e-5, atol=3e-6, err_msg=k)
+
+
+def test_g11_points_only_head():
+    """comp2's env_light_network: constructor parity (seed 7) and the points_only forward (fields.py:203-239)."""
+    from iron_amd.network_conf import comp_env_light_network
+    from _util import cpu_sd
+    torch.manual_seed(7)
+    env = comp_env_light_network()
+    assert state_hash({"env_light_network": env}) == golden_meta()["state_sha256_env_light"]
+    g = golden("g11_points_only.npz")
+    spec = R.RenderSpec(d_in=3, d_out=1, n_layers=4, multires=6, multires_view=-1, mode="points_only", squeeze_out=False)
+    out = R.rendering_forward(cpu_sd(env), spec, t(g["points"]), None, None, t(g["features"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=1e-6)
