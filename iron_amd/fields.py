@@ -12,7 +12,6 @@ Only inference is built (autograd through the kernels is a lat
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch

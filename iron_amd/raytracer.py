@@ -16,7 +16,7 @@ There is no CPU path: tensors must be CUDA (ROCm) fp32.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Dict, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -11,7 +11,6 @@ coherent; weights (5.4 MB) are replicated.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -147,7 +146,6 @@ class ShardedRenderer:
 
     @torch.no_grad()
     def render(self, cameras, collect_stats: bool = False):
-        from . import _lib
         from .raytracer import SDFHandle, intersect_sphere
         H, W = cameras[0].H, cameras[0].W
         dev = cameras[0].device

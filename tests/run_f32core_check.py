@@ -3,8 +3,6 @@ when the library decides its backend) against the reference goldens."""
 import os
 import sys
 
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -6,7 +6,7 @@ import torch
 from oracle import iron_ref as R
 from iron_amd import scenes
 
-from _util import golden, oracle_scene, rel_l2, t, tables
+from _util import golden, oracle_scene, rel_l2, t
 
 pytestmark = pytest.mark.gpu
 

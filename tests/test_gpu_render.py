@@ -11,13 +11,12 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import iron_ref as R
 from iron_amd import scenes
 from iron_amd.raytracer import Camera, RayTracer, render_camera, render_normal_and_color
 from iron_amd.renderer_ggx import GGXColocatedRenderer
 from iron_amd.rendering_func import get_materials, make_render_fn
 
-from _util import golden, golden_meta, oracle_scene, rel_l2, t
+from _util import golden, oracle_scene, rel_l2, t
 
 pytestmark = pytest.mark.gpu
 
