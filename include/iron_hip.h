@@ -161,6 +161,13 @@ int iron_coloc_head(int32_t kind, float light, float eta, float k, const float* 
 int iron_morph_closing3x3(const float* depth, int32_t H, int32_t W, float* tmp, float* out, void* stream);
 int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, float* out, void* stream);
 
+/* The surface walk of locate_edge_points (models/raytracer.py:441-478) in one launch: every start point walks along
+ * the surface (step_size per step, at most max_step steps) until |n.v| <= dot_threshold seen from cam_origin3 (HOST
+ * float[3]); points [n,3] receives the final positions, found [n] whether the silhouette was reached.  Needs the h2
+ * core for this network (IRON_ERR_UNSUPPORTED otherwise: walk with iron_sdf_get_all instead). */
+int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t n, const float* cam_origin3, int32_t max_step,
+                   float step_size, float dot_threshold, float* points, uint8_t* found, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sphere tracer.  Replaces RayTracer.forward = sphere_tracing + ray_sampler + rootfind
  * (models/raytracer.py:45-220) for a batch of n rays, with the per-call chunking of

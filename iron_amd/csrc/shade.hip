@@ -193,48 +193,31 @@ __device__ __forceinline__ void lds_publish_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m, GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds = smem;
-    const int lane = threadIdx.x & 63;
+// One evaluation of value (wave 0) or tangent d/d axis (waves 1-3) of the SDF network at this lane's point on the h2
+// ring (the trace stream: 72 slots).  Returns the sdf (value wave) or the gradient component (tangent waves); `out` is
+// left holding the last hidden layer as f32 bit patterns (for the feature rows).  All four waves call it together.
+__device__ __forceinline__ float sdf_value_or_tangent_h2(Ring& ring, char* lds, float* sbuf, const H2Meta& m, float px, float py,
+                                                         float pz, bool is_value, int axis, int wave, int lane,
+                                                         TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles]) {
     const int half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_value = wave == 0;
-    const int axis = wave - 1;
-    Ring ring;
-    h2_setup(hs, lds, ring);
-    float* sbuf = reinterpret_cast<float*>(lds + kLdsSbuf);
-    const int count = a.count_ptr ? *a.count_ptr : a.count;
-    const int n_tiles = (count + kTile - 1) / kTile;
-    const bool want_feat = (a.feat_packed != nullptr) || (a.feat_rows != nullptr);
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int li = tile * kTile + (lane & 31);
-        const bool ok = li < count;
-        const int src = ok ? (a.list ? a.list[li] : li) : 0;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (ok) { px = a.x[3 * (size_t)src]; py = a.x[3 * (size_t)src + 1]; pz = a.x[3 * (size_t)src + 2]; }
-        const float sx = px * m.scale, sy = py * m.scale, sz = pz * m.scale;
-
-        float head[kHeadSlots];
+    const float sx = px * m.scale, sy = py * m.scale, sz = pz * m.scale;
+    float head[kHeadSlots];
 #pragma unroll
-        for (int i = 0; i < kHeadSlots; ++i) head[i] = 0.0f;
-        if (is_value) head_fill<kSdfPeLevels>(sx, sy, sz, half, head);
-        else head_fill_tangent<kSdfPeLevels>(sx, sy, sz, axis, half, head);
-        HeadFrag hd;
-        split_head(head, hd);
-
-        TileFrag in[kHidTiles], out[kHidTiles];
-        TileFrag dummy_out;
-        f32x16 dummy_hf;
-        for (int l = 0; l < m.n_hidden_layers; ++l) {
-            const bool last = (l == m.n_hidden_layers - 1);
-            const bool with_head = (l == 0) || (l == m.skip_layer);
-            const char* bias = lds + kLdsBias + l * 1024;
-            if (l > 0) {
+    for (int i = 0; i < kHeadSlots; ++i) head[i] = 0.0f;
+    if (is_value) head_fill<kSdfPeLevels>(sx, sy, sz, half, head);
+    else head_fill_tangent<kSdfPeLevels>(sx, sy, sz, axis, half, head);
+    HeadFrag hd;
+    split_head(head, hd);
+    TileFrag dummy_out;
+    f32x16 dummy_hf;
+    for (int l = 0; l < m.n_hidden_layers; ++l) {
+        const bool last = (l == m.n_hidden_layers - 1);
+        const bool with_head = (l == 0) || (l == m.skip_layer);
+        const char* bias = lds + kLdsBias + l * 1024;
+        if (l > 0) {
 #pragma unroll
-                for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
-            }
+            for (int t = 0; t < kHidTiles; ++t) in[t] = out[t];
+        }
 #define IRON_GTILE(TO)                                                                                                  \
     {                                                                                                                   \
         f32x16 a_hi = zero16(), a_lo = zero16();                                                                        \
@@ -268,25 +251,51 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m
         if (last) out[TO] = __builtin_bit_cast(TileFrag, zt);                                                           \
         else split_tile(zt, out[TO]);                                                                                   \
     }
-            IRON_GTILE(0) IRON_GTILE(1) IRON_GTILE(2) IRON_GTILE(3) IRON_GTILE(4) IRON_GTILE(5) IRON_GTILE(6) IRON_GTILE(7)
+        IRON_GTILE(0) IRON_GTILE(1) IRON_GTILE(2) IRON_GTILE(3) IRON_GTILE(4) IRON_GTILE(5) IRON_GTILE(6) IRON_GTILE(7)
 #undef IRON_GTILE
-        }
-
-        f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
+    }
+    f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
 #pragma unroll
-        for (int t = 0; t < kHidTiles; ++t) hf[t] = __builtin_bit_cast(f32x16, out[t]);
+    for (int t = 0; t < kHidTiles; ++t) hf[t] = __builtin_bit_cast(f32x16, out[t]);
+    const float d = row_dot_lds(lds + kLdsRows, hf, half);
+    return is_value ? (d + m.b_last) / m.scale : d;
+}
+
+__global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m, GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_value = wave == 0;
+    const int axis = wave - 1;
+    Ring ring;
+    h2_setup(hs, lds, ring);
+    float* sbuf = reinterpret_cast<float*>(lds + kLdsSbuf);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+    const bool want_feat = (a.feat_packed != nullptr) || (a.feat_rows != nullptr);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int src = ok ? (a.list ? a.list[li] : li) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (ok) { px = a.x[3 * (size_t)src]; py = a.x[3 * (size_t)src + 1]; pz = a.x[3 * (size_t)src + 2]; }
+        TileFrag in[kHidTiles], out[kHidTiles];
+        const float res = sdf_value_or_tangent_h2(ring, lds, sbuf, m, px, py, pz, is_value, axis, wave, lane, in, out);
         if (is_value) {
-            const float s = (row_dot_lds(lds + kLdsRows, hf, half) + m.b_last) / m.scale;
-            if (ok && lane < 32 && a.sdf_out) a.sdf_out[li] = s;
+            if (ok && lane < 32 && a.sdf_out) a.sdf_out[li] = res;
         } else {
-            const float g = row_dot_lds(lds + kLdsRows, hf, half);
-            if (ok && lane < 32 && a.grad_out) a.grad_out[3 * (size_t)li + axis] = g;
+            if (ok && lane < 32 && a.grad_out) a.grad_out[3 * (size_t)li + axis] = res;
         }
         // feature rows: 8 more ring slots (every wave steps the ring; only the value wave multiplies)
         if (want_feat) {
+            TileFrag dummy_out;
+            f32x16 dummy_hf;
             if (is_value) {
 #pragma unroll
-                for (int t = 0; t < kHidTiles; ++t) split_tile(hf[t], in[t]);
+                for (int t = 0; t < kHidTiles; ++t) split_tile(__builtin_bit_cast(f32x16, out[t]), in[t]);
             }
             const char* fb = lds + kLdsBias + m.n_hidden_layers * 1024;
             float* dst = a.feat_packed ? a.feat_packed + (size_t)tile * kSBufFloats : nullptr;
@@ -310,6 +319,72 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m
     }
             IRON_FTILE(0) IRON_FTILE(1) IRON_FTILE(2) IRON_FTILE(3) IRON_FTILE(4) IRON_FTILE(5) IRON_FTILE(6) IRON_FTILE(7)
 #undef IRON_FTILE
+        }
+    }
+    ring.drain();
+}
+
+// locate_edge_points' walk (models/raytracer.py:421-478) for 32 candidates per workgroup, all <= max_step + 1
+// evaluations inside ONE launch: every candidate is an independent state machine (a found point never moves again),
+// so the tile loops until all of its points are found or the step budget is spent.  Value + three tangent waves as in
+// k_sdf_grad_h2; s, g are exchanged through LDS and every wave repeats the (cheap) update so that all four agree on
+// the new positions and on the loop exit.
+struct WalkArgs {
+    const float* start;   // [n,3]
+    int n;
+    float cam[3];
+    int max_step;
+    float step_size, dot_threshold;
+    float* points;        // [n,3] final positions
+    uint8_t* found;       // [n]
+};
+
+__global__ __launch_bounds__(256, 1) void k_edge_walk_h2(H2StreamDev hs, H2Meta m, WalkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_value = wave == 0;
+    const int axis = wave - 1;
+    Ring ring;
+    h2_setup(hs, lds, ring);
+    float* sbuf = reinterpret_cast<float*>(lds + kLdsSbuf);
+    float* xch = reinterpret_cast<float*>(lds + kLdsGradTotal);  // [4][32]: s, gx, gy, gz of the tile's points
+    const int n_tiles = (a.n + kTile - 1) / kTile;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < a.n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (ok) { px = a.start[3 * (size_t)li]; py = a.start[3 * (size_t)li + 1]; pz = a.start[3 * (size_t)li + 2]; }
+        bool found = !ok;  // padding lanes never keep the tile alive
+        for (int it = 0;; ++it) {
+            TileFrag in[kHidTiles], out[kHidTiles];
+            const float res = sdf_value_or_tangent_h2(ring, lds, sbuf, m, px, py, pz, is_value, axis, wave, lane, in, out);
+            if (lane < 32) xch[wave * 32 + lane] = res;
+            lds_publish_barrier();
+            const float s = xch[lane & 31], gx = xch[32 + (lane & 31)], gy = xch[64 + (lane & 31)], gz = xch[96 + (lane & 31)];
+            // raytracer.py:449-459
+            float vx = a.cam[0] - px, vy = a.cam[1] - py, vz = a.cam[2] - pz;
+            const float vn = sqrtf((vx * vx + vy * vy) + vz * vz) + 1e-10f;
+            vx /= vn; vy /= vn; vz /= vn;
+            const float gn = sqrtf((gx * gx + gy * gy) + gz * gz) + 1e-10f;
+            const float nx = gx / gn, ny = gy / gn, nz = gz / gn;
+            const float dot = (nx * vx + ny * vy) + nz * vz;
+            const bool moving = !found && (fabsf(dot) > a.dot_threshold);  // a NaN dot counts as found, as in the reference
+            found = !moving;
+            const bool any_moving = __ballot(moving) != 0ull;  // identical in the four waves (same inputs, same arithmetic)
+            __syncthreads();                                  // xch is rewritten by the next evaluation
+            if (it >= a.max_step || !any_moving) break;
+            if (moving) {  // raytracer.py:468-474
+                float wx = nx - vx / dot, wy = ny - vy / dot, wz = nz - vz / dot;
+                const float wn = sqrtf((wx * wx + wy * wy) + wz * wz) + 1e-10f;
+                wx = wx / wn - s * nx; wy = wy / wn - s * ny; wz = wz / wn - s * nz;
+                px += a.step_size * wx; py += a.step_size * wy; pz += a.step_size * wz;
+            }
+        }
+        if (ok && wave == 0 && lane < 32) {
+            a.points[3 * (size_t)li] = px; a.points[3 * (size_t)li + 1] = py; a.points[3 * (size_t)li + 2] = pz;
+            a.found[li] = found ? 1 : 0;
         }
     }
     ring.drain();
@@ -749,6 +824,32 @@ extern "C" int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n
     a.x = x; a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n;
     a.feat_packed = nullptr; a.sdf_out = sdf_out; a.grad_out = grad; a.feat_rows = feature;
     return launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+}
+
+extern "C" int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t n, const float* cam_origin3, int32_t max_step,
+                              float step_size, float dot_threshold, float* points, uint8_t* found, void* stream) {
+    if (!sdf || sdf->desc.kind != IRON_NET_SDF || n < 0 || max_step < 0 || !cam_origin3) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!start || !points || !found) return IRON_ERR_BAD_ARG;
+    if (!h2_sdf_usable(sdf)) return IRON_ERR_UNSUPPORTED;  // the caller then walks with iron_sdf_get_all launches
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_edge_walk_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsGradTotal + 512));
+        attr = true;
+    }
+    H2Meta m;
+    m.n_hidden_layers = sdf->sdf.n_hidden_layers; m.skip_layer = sdf->sdf.skip_layer; m.scale = sdf->sdf.scale; m.b_last = sdf->sdf.b_last;
+    WalkArgs a;
+    a.start = start; a.n = (int)n; a.cam[0] = cam_origin3[0]; a.cam[1] = cam_origin3[1]; a.cam[2] = cam_origin3[2];
+    a.max_step = max_step; a.step_size = step_size; a.dot_threshold = dot_threshold; a.points = points; a.found = found;
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    const int cus = cu_count();
+    ProfScope ps(IRON_PROF_SDF_GRAD, st);
+    hipLaunchKernelGGL(k_edge_walk_h2, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), kLdsGradTotal + 512, st, sdf->h2_trace, m, a);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
 }
 
 extern "C" int iron_render_forward(const iron_net_t* net, const float* points, const float* normals,

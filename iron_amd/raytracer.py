@@ -299,6 +299,22 @@ def sobel_magnitude(depth):
     return out
 
 
+def _edge_walk_fused(sdf_network, start, cam_o, max_step, step_size, dot_threshold):
+    """The whole walk in one kernel (iron_edge_walk); None when the network cannot run on the h2 core."""
+    n = start.shape[0]
+    dev = start.device
+    points = torch.empty_like(start)
+    found = torch.empty(n, dtype=torch.uint8, device=dev)
+    cam = (C.c_float * 3)(*cam_o.reshape(-1).tolist())
+    with torch.cuda.device(dev):
+        rc = _lib.load().iron_edge_walk(sdf_network.hip_net().handle, start.data_ptr(), n, cam, int(max_step), float(step_size),
+                                        float(dot_threshold), points.data_ptr(), found.data_ptr(), _lib.stream_ptr(dev))
+    if rc == _lib.IRON_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return points, found.bool()
+
+
 @torch.no_grad()
 def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_size, dot_threshold, max_num_rays=200000,
                        mask=None):
@@ -315,20 +331,24 @@ def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_si
     found = torch.zeros(cur.shape[0], dtype=torch.bool, device=dev)
     if cur.shape[0] > 0:
         cam_o = camera.get_camera_origin().reshape(1, 3)
-        for i in range(max_step + 1):
-            sdf, grad = sdf_network.get_sdf_and_gradient(cur)
-            view = cam_o - cur
-            view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
-            nrm = grad / (grad.norm(dim=-1, keepdim=True) + 1e-10)
-            dot = (nrm * view).sum(dim=-1)
-            # a found point keeps its position, hence its dot: OR-ing equals the reference's masked update
-            found |= dot.abs() <= dot_threshold
-            if i >= max_step or (i % 4 == 3 and bool(found.all())):
-                break
-            walk = nrm - view / dot.unsqueeze(-1)
-            walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
-            walk = walk - sdf * nrm
-            cur = torch.where(found.unsqueeze(-1), cur, cur + step_size * walk)
+        fused = _edge_walk_fused(sdf_network, cur, cam_o, max_step, step_size, dot_threshold)
+        if fused is not None:
+            cur, found = fused
+        else:  # network not on the h2 core: the same walk, one get_all launch per step
+            for i in range(max_step + 1):
+                sdf, grad = sdf_network.get_sdf_and_gradient(cur)
+                view = cam_o - cur
+                view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+                nrm = grad / (grad.norm(dim=-1, keepdim=True) + 1e-10)
+                dot = (nrm * view).sum(dim=-1)
+                # a found point keeps its position, hence its dot: OR-ing equals the reference's masked update
+                found |= ~(dot.abs() > dot_threshold)
+                if i >= max_step or (i % 4 == 3 and bool(found.all())):
+                    break
+                walk = nrm - view / dot.unsqueeze(-1)
+                walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
+                walk = walk - sdf * nrm
+                cur = torch.where(found.unsqueeze(-1), cur, cur + step_size * walk)
     edge_points = cur[found]
     edge_mask = camera.get_uv().new_zeros(camera.H, camera.W).bool()
     edge_uv = torch.zeros_like(edge_points[..., :2])
