@@ -1,20 +1,27 @@
 #!/bin/bash
-# PMC passes on the batched SDF-MLP micro-benchmark (tools/bench_mlp.py); IRON_MLP_CORE selects the core.
-set -o pipefail
+# Stall-breakdown PMC passes on the batched SDF-MLP kernel (tools/bench_mlp.py); each pass is independent.
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/prof_mlp"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/tools/bench_mlp.py --n 2097152 --iters 2"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/p1" -o m -- python3 $ARGS > "$OUT/p1.log" 2>&1 || { tail -5 "$OUT/p1.log"; exit 1; }
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/p2" -o m -- python3 $ARGS > "$OUT/p2.log" 2>&1 || { tail -5 "$OUT/p2.log"; exit 1; }
+rocprofv3 -L > "$OUT/avail.txt" 2>&1
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
+           "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_WAVES" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL" \
+           "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TA_TCP_STATE_READ_sum"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -o m -- python3 $ARGS > "$OUT/p$i.log" 2>&1 || echo "pass $i failed: $(tail -2 $OUT/p$i.log)"
+done
 python3 - <<PY
-import csv, collections
-for d in ("p1","p2"):
+import csv, collections, glob
+for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open("$OUT/%s/m_counter_collection.csv" % d)):
+    for r in csv.DictReader(open(f)):
         if "k_sdf_values" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        print("%-28s %.4g" % (k, sum(v)/len(v)))
+        print("%-32s %.5g" % (k, sum(v)/len(v)))
 PY
