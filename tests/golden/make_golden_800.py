@@ -1,0 +1,69 @@
+"""Golden for BASELINE.json's full-size configuration C1 (S0, 800x800) -- BUILD CONTAINER ONLY (minutes of CPU).
+
+Runs the real reference's render_camera (fill_holes=False, handle_edges=False) at 800x800 in fp32 and fp64 and stores
+what a full-size parity test needs in a small file: the complete hit mask (bit-packed), and colour / normal / distance on
+the pixel sub-lattice [::4, ::4] (40 000 pixels) for both precisions, plus the fp32-vs-fp64 floor over ALL pixels.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_800.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402
+
+from models.raytracer import RayTracer, render_camera  # noqa: E402  (reference)
+from models.renderer_ggx import GGXColocatedRenderer  # noqa: E402
+
+RES, STRIDE = 800, 4
+
+
+def run(dtype):
+    nets = MG.build_reference_networks("S0")
+    if dtype == torch.float64:
+        nets = {k: v.double() for k, v in nets.items()}
+        cam32 = MG.fixture_camera(RES, RES)
+        cam = MG.Camera64(RES, RES, cam32.K.double(), cam32.W2C.double())
+    else:
+        cam = MG.fixture_camera(RES, RES)
+    renderer = GGXColocatedRenderer(use_cuda=False)  # fp32 tables in both runs, as make_golden.py's fp64 runs
+    fn = MG.make_render_fn(nets, renderer, dtype)
+    t0 = time.time()
+    with torch.no_grad():
+        res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=False, handle_edges=False,
+                            is_training=False)
+    print(dtype, "%.0f s" % (time.time() - t0), "hits", int(res["convergent_mask"].sum()), flush=True)
+    return res
+
+
+def main():
+    r32 = run(torch.float32)
+    r64 = run(torch.float64)
+    m32, m64 = r32["convergent_mask"].numpy(), r64["convergent_mask"].numpy()
+    both = m32 & m64
+    c32, c64 = r32["color"].numpy().astype(np.float64), r64["color"].numpy()
+    floor = float(np.linalg.norm(c32[both] - c64[both]) / np.linalg.norm(c64[both]))
+    out = {"mask_bits": np.packbits(m32.reshape(-1)), "mask64_bits": np.packbits(m64.reshape(-1)), "res": np.int64(RES),
+           "stride": np.int64(STRIDE)}
+    for k in ("color", "normal", "distance"):
+        out[k] = r32[k].numpy()[::STRIDE, ::STRIDE].astype(np.float32)
+        out[k + "_fp64"] = r64[k].numpy()[::STRIDE, ::STRIDE].astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, "g12_S0_800.npz"), **out)
+    meta_path = os.path.join(HERE, "meta.json")
+    meta = json.load(open(meta_path))
+    meta.update({"n_conv_S0_800": int(m32.sum()), "mask_flips_ref32_ref64_S0_800": int((m32 != m64).sum()),
+                 "colour_rel_l2_ref32_ref64_S0_800": floor})
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print({k: meta[k] for k in ("n_conv_S0_800", "mask_flips_ref32_ref64_S0_800", "colour_rel_l2_ref32_ref64_S0_800")})
+
+
+if __name__ == "__main__":
+    main()

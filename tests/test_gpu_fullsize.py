@@ -193,3 +193,32 @@ def test_fullsize_silhouette_handling_invariants(frame800):
     # hole filling is idempotent on its own output
     d2 = morph_closing3x3(depth)
     assert torch.equal(d2, depth)
+
+
+def test_fullsize_vs_reference_golden(frame800):
+    """BASELINE config C1 itself against the REAL reference (tests/golden/make_golden_800.py: fp32 and fp64 runs of the
+    reference's render_camera at 800x800): the complete hit mask, and colour / normal / distance on the [::4, ::4]
+    sub-lattice.  Target (BASELINE.json north_star): colour rel-L2 <= 1e-4 vs the reference; like at 128^2 the bound is read
+    against the reference's own fp32-vs-fp64 figure on the same pixels."""
+    from _util import golden, golden_meta, rel_l2
+    _, _, _, res, _ = frame800
+    g = golden("g12_S0_800.npz")
+    n = int(g["res"]); st = int(g["stride"])
+    mask_ref = np.unpackbits(g["mask_bits"])[: n * n].astype(bool).reshape(n, n)
+    conv = res["convergent_mask"].cpu().numpy()
+    flips = int((conv != mask_ref).sum())
+    flips_ref = golden_meta()["mask_flips_ref32_ref64_S0_800"]
+    sub = (slice(None, None, st), slice(None, None, st))
+    both = conv[sub] & mask_ref[sub] & np.unpackbits(g["mask64_bits"])[: n * n].astype(bool).reshape(n, n)[sub]
+    col = res["color"].cpu().numpy()[sub]
+    r32 = rel_l2(col[both], g["color"][both])
+    r64 = rel_l2(col[both], g["color_fp64"][both])
+    floor = rel_l2(g["color"][both], g["color_fp64"][both])
+    dist = np.abs(res["distance"].cpu().numpy()[sub][both] - g["distance"][both])
+    print("800x800 S0: mask flips %d (reference fp32 vs fp64: %d)  colour rel-L2 hip~ref32 %.3e  hip~ref64 %.3e  ref32~ref64 %.3e"
+          "  |d distance| p99 %.2e max %.2e" % (flips, flips_ref, r32, r64, floor, np.percentile(dist, 99), dist.max()))
+    assert int(conv.sum()) == golden_meta()["n_conv_S0_800"]
+    assert flips <= max(2, 2 * flips_ref)
+    assert r32 <= max(1e-4, 1.5 * floor), (r32, floor)
+    assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
+    assert np.percentile(dist, 99) <= 2e-4
