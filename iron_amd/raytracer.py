@@ -39,6 +39,46 @@ class SDFHandle:
         return self.sdf_network.sdf(x)[..., 0]
 
 
+def _resolve_sdf_network(sdf, device):
+    """The SDFNetwork behind the `sdf` callable of RayTracer.forward.  The reference hands over a lambda
+    (`lambda x: sdf_network(x)[..., 0]`, raytracer.py:375); the HIP tracer needs the network itself, so:
+      * an SDFHandle (what raytrace_pixels makes) or anything with an `.sdf_network` attribute is taken as is;
+      * a bound method of a network, or a function whose closure / defaults hold exactly one network, is accepted
+        only after a probe: the callable and the network must agree on 64 random points (a lambda that post-processes
+        the distance would otherwise be traced wrongly without notice).
+    Anything else is refused."""
+    net = getattr(sdf, "sdf_network", None)
+    if net is not None and hasattr(net, "hip_net"):
+        return net
+    cands = []
+    owner = getattr(sdf, "__self__", None)
+    if owner is not None and hasattr(owner, "hip_net"):
+        cands.append(owner)
+    for cell in (getattr(sdf, "__closure__", None) or ()):
+        try:
+            v = cell.cell_contents
+        except ValueError:
+            continue
+        if hasattr(v, "hip_net") and hasattr(v, "sdf"):
+            cands.append(v)
+    for v in (getattr(sdf, "__defaults__", None) or ()):
+        if hasattr(v, "hip_net") and hasattr(v, "sdf"):
+            cands.append(v)
+    cands = list({id(c): c for c in cands}.values())
+    if len(cands) != 1:
+        raise _lib.IronError("RayTracer.forward needs the sdf handle made by raytrace_pixels / SDFHandle(sdf_network), or a "
+                             "callable that wraps exactly one iron_amd SDFNetwork; opaque sdf callables cannot run on the HIP tracer")
+    net = cands[0]
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(64, 3, generator=g) * 1.6 - 0.8).to(device)
+    got = torch.as_tensor(sdf(x)).reshape(-1)
+    want = net.sdf(x)[..., 0].reshape(-1)
+    if got.shape != want.shape or not torch.allclose(got, want, rtol=1e-5, atol=1e-6):
+        raise _lib.IronError("the sdf callable does not return sdf_network.sdf(x)[..., 0] of the network it wraps; "
+                             "pass SDFHandle(sdf_network)")
+    return net
+
+
 def _linspace_steps(n_steps: int, device) -> torch.Tensor:
     # torch.linspace(0, 1, n_steps).float() exactly as raytracer.py:144-146 builds it
     return torch.linspace(0, 1, steps=n_steps).float().to(device)
@@ -67,11 +107,8 @@ class RayTracer(nn.Module):
 
         `chunk` (extension): rays [k*chunk,(k+1)*chunk) are treated as separate reference calls
         (they share the bisection iteration count, raytracer.py:204-217); 0 = the whole batch."""
-        net = getattr(sdf, "sdf_network", None)
-        if net is None or not hasattr(net, "hip_net"):
-            raise _lib.IronError("RayTracer.forward needs the sdf handle made by raytrace_pixels / SDFHandle(sdf_network); "
-                                 "opaque sdf callables are not supported by the HIP tracer")
         o = _lib.require_cuda_f32(ray_o, "ray_o").reshape(-1, 3)
+        net = _resolve_sdf_network(sdf, o.device)
         d = _lib.require_cuda_f32(ray_d, "ray_d").reshape(-1, 3)
         near = _lib.require_cuda_f32(min_dis, "min_dis").reshape(-1)
         far = _lib.require_cuda_f32(max_dis, "max_dis").reshape(-1)
@@ -107,10 +144,8 @@ class RayTracer(nn.Module):
         chunk-global bisection count is exchanged between the two halves.  `ray_index` [n] int64 = position of
         each ray in the whole job (chunk id = ray_index // chunk); `reduce_fn(int32[n_chunks])` must MAX-reduce
         the table over the ranks in place (iron_amd.sharding.reduce_chunk_iters)."""
-        net = getattr(sdf, "sdf_network", None)
-        if net is None or not hasattr(net, "hip_net"):
-            raise _lib.IronError("forward_phased needs SDFHandle(sdf_network)")
         o = _lib.require_cuda_f32(ray_o, "ray_o").reshape(-1, 3)
+        net = _resolve_sdf_network(sdf, o.device)
         d = _lib.require_cuda_f32(ray_d, "ray_d").reshape(-1, 3)
         near = _lib.require_cuda_f32(min_dis, "min_dis").reshape(-1)
         far = _lib.require_cuda_f32(max_dis, "max_dis").reshape(-1)

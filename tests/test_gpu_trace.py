@@ -98,6 +98,18 @@ def test_chunk_semantics_and_direct_forward():
     assert flips <= 2
     both = conv & ref["convergent_mask"].numpy()
     assert np.abs(out["distance"].cpu().numpy() - ref["distance"].numpy())[both].max() <= 2e-4
+    # the reference's own calling convention (raytracer.py:375: a lambda around the network) gives the same result;
+    # a lambda that alters the distance, or one that wraps no network, is refused instead of being traced wrongly
+    from iron_amd import _lib
+    out_l = RayTracer()(lambda x: sdf(x)[..., 0], o, d, near, far, m)
+    for k in ("convergent_mask", "distance", "points", "sdf"):
+        assert torch.equal(out_l[k], out[k]), k
+    out_b = RayTracer()(lambda x: sdf.sdf(x)[..., 0], o, d, near, far, m)
+    assert torch.equal(out_b["distance"], out["distance"])
+    with pytest.raises(_lib.IronError):
+        RayTracer()(lambda x: sdf(x)[..., 0] - 0.01, o, d, near, far, m)
+    with pytest.raises(_lib.IronError):
+        RayTracer()(lambda x: x.norm(dim=-1) - 0.5, o, d, near, far, m)
     # empty batch
     e = torch.zeros(0, 3, device="cuda")
     out0 = RayTracer()(SDFHandle(sdf), e, e, e[:, 0], e[:, 0], torch.zeros(0, dtype=torch.bool, device="cuda"))
