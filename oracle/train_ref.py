@@ -1,0 +1,63 @@
+"""CPU restatement of the reference's stage-2 TRAINING forward (BASELINE config C3) -- TEST
+INFRASTRUCTURE ONLY (same import rule as oracle/iron_ref.py).  No product code exists for this row yet: the restatement and
+its goldens (tests/golden/make_golden_train.py; tests/test_oracle_train.py) fix what the HIP backward will be held to.
+
+What differs from the inference path (oracle/iron_ref.py), line for line:
+    models/raytracer.py:17-24     reparam_points: the (non-differentiable) hit point is made a function of the SDF
+                                  parameters through x - d / max(n.d, 1e-4) * (sdf(x) - sdf(x).detach())
+    models/fields.py:120-137      get_all(is_training=True): autograd.grad(..., create_graph=True) -> the normal carries
+                                  second-order dependence on the SDF parameters
+    models/raytracer.py:622-646   render_normal_and_color(is_training=True): render_fn under grad mode
+Gradients are then whatever torch.autograd makes of this graph; the parameters are passed as leaf tensors that require
+grad (a state_dict of such leaves), every op below is differentiable torch code.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+from torch import Tensor
+
+from . import iron_ref as R
+
+
+def leaf_state(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """state_dict -> same keys, leaf tensors with requires_grad (floating-point entries only)."""
+    return {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+
+def reparam_points(points: Tensor, grads: Tensor, dirs: Tensor, sdf_vals: Tensor) -> Tensor:
+    """raytracer.py:17-24."""
+    dot = torch.clamp((grads * dirs).sum(dim=-1, keepdim=True), min=1e-4)
+    return points - dirs / dot * (sdf_vals - sdf_vals.detach())
+
+
+def sdf_get_all_train(sd: Dict[str, Tensor], spec: R.SDFSpec, x: Tensor):
+    """fields.py:120-137 with is_training=True: (sdf, feature, gradient), all attached to the graph."""
+    with torch.enable_grad():
+        xg = x.detach().clone().requires_grad_(True)
+        out = R.sdf_forward(sd, spec, xg)
+        y, feat = out[..., :1], out[..., 1:]
+        (grad,) = torch.autograd.grad(y, xg, torch.ones_like(y), create_graph=True, retain_graph=True, only_inputs=True)
+    return y, feat, grad
+
+
+def render_camera_train(scene: R.Scene, cam: R.CameraSpec) -> Dict[str, Tensor]:
+    """render_camera(fill_holes=False, handle_edges=False, is_training=True), raytracer.py:778-814: the trace runs without
+    grad (raytracer.py:542 @torch.no_grad), shading with it.  `scene`'s state dicts must be leaf_state()s."""
+    with torch.no_grad():
+        res = R.raytrace_camera(scene, cam, max_num_rays=50000)
+    sh = list(res["convergent_mask"].shape)
+    m = res["convergent_mask"].reshape(-1)
+    assert bool(m.any()), "the golden crop has hits"
+    p = res["points"].reshape(-1, 3)[m]
+    d = res["ray_d"].reshape(-1, 3)[m]
+    o = res["ray_o"].reshape(-1, 3)[m]
+    sdf, feat, grad = sdf_get_all_train(scene.sdf_sd, scene.sdf_spec, p)
+    p = reparam_points(p, grad.detach(), -d.detach(), sdf)
+    with torch.enable_grad():
+        r = R.render_fn_ggx(scene, m, o, d, p, grad, feat)
+    for k, v in r.items():
+        v = v.reshape(sh + [-1])
+        res[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+    return res
