@@ -31,7 +31,7 @@ BASE_FLAGS = [
 
 # Accumulators of the h2 kernels in VGPRs (no v_accvgpr_read in front of the epilogue, 3-5x less scratch).  The pass
 # behind this option has crashed hipcc 7.2 on some revisions of trace.hip; a source that fails with it is recompiled
-# without it (the kernels are correct either way, only slower).
+# with weaker flag sets (see compile_one; the kernels are correct either way, only slower).
 OPTIONAL_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
@@ -67,11 +67,16 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         tail = ["-c", os.path.join(CSRC, src), "-o", obj]
-        r = subprocess.run([hipcc] + BASE_FLAGS + OPTIONAL_FLAGS + extra_flags + tail, capture_output=True, text=True)
-        if r.returncode != 0:
-            if verbose:
-                print("build: %s failed with %s, retrying without" % (src, " ".join(OPTIONAL_FLAGS)), file=sys.stderr)
-            r = subprocess.run([hipcc] + BASE_FLAGS + extra_flags + tail, capture_output=True, text=True)
+        # flag sets tried in order: the full set; the same with the sampler's tile deferral off (the one construct the
+        # vgpr-form pass has crashed on); finally without the vgpr-form option
+        attempts = [OPTIONAL_FLAGS, OPTIONAL_FLAGS + ["-DIRON_SAMPLER_DEFER=0"], []]
+        r = None
+        for i, opt in enumerate(attempts):
+            r = subprocess.run([hipcc] + BASE_FLAGS + opt + extra_flags + tail, capture_output=True, text=True)
+            if r.returncode == 0:
+                break
+            if verbose and i + 1 < len(attempts):
+                print("build: %s failed with [%s], retrying with [%s]" % (src, " ".join(opt), " ".join(attempts[i + 1])), file=sys.stderr)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         return obj
