@@ -16,6 +16,7 @@ from iron_amd.raytracer import Camera, RayTracer, render_camera, render_normal_a
 from iron_amd.renderer_ggx import GGXColocatedRenderer
 from iron_amd.rendering_func import get_materials, make_render_fn
 
+from oracle import iron_ref as R
 from _util import golden, oracle_scene, rel_l2, t
 
 pytestmark = pytest.mark.gpu
@@ -132,3 +133,32 @@ def test_training_fails_loudly():
     _, nets, cam, fn, _ = _render("S0", "c0")
     with pytest.raises(NotImplementedError):
         render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, handle_edges=False, is_training=True)
+
+
+@pytest.mark.parametrize("seed,sigma,yaw", [(2, 0.008, 20.0), (3, 0.012, 135.0), (4, 0.016, 250.0)])
+def test_random_scenes_vs_oracle(seed, sigma, yaw):
+    """Beyond the two golden scenes: freshly seeded networks (own SDF perturbation, own material nets) and an orbited
+    camera, HIP vs the pinned oracle at 48x48.  Flips are counted, colour is compared on the common hits."""
+    torch.manual_seed(seed)
+    nets = scenes.build_networks("S0", seed=seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    v = nets["sdf_network"].lin0.weight_v
+    with torch.no_grad():
+        v[:, 3:] += sigma * torch.randn(v[:, 3:].shape, generator=g)
+    sc = oracle_scene(nets, light=float(nets["point_light_network"]()))
+    K, W2C = scenes.fixture_camera_matrices(48, 48, yaw_deg=yaw)
+    ref = R.render_camera(sc, R.CameraSpec(48, 48, K, W2C))
+    gpu = {k: m.cuda() for k, m in nets.items()}
+    cam = Camera(48, 48, K.cuda(), W2C.cuda())
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    res = render_camera(cam, gpu["sdf_network"], RayTracer(), gpu, fn, fill_holes=False, handle_edges=False)
+    conv, rconv = res["convergent_mask"].cpu().numpy(), ref["convergent_mask"].numpy()
+    flips = int((conv != rconv).sum())
+    both = conv & rconv
+    assert both.sum() > 200
+    r = rel_l2(res["color"].cpu().numpy()[both], ref["color"].numpy()[both])
+    d = np.abs(res["distance"].cpu().numpy() - ref["distance"].numpy())[both]
+    print("seed %d sigma %.3f yaw %.0f: hits %d flips %d colour rel-L2 %.2e |d distance| p99 %.2e" % (seed, sigma, yaw, int(both.sum()), flips, r, np.percentile(d, 99)))
+    assert flips <= 2
+    assert r <= 2e-4
+    assert np.percentile(d, 99) <= 2e-4
