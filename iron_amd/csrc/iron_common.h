@@ -56,7 +56,7 @@ struct SdfNetDev {
     int skip_layer;           // 4
 };
 
-// Material net: head (<= 6 quads of slots) + 256 features -> 256 x (n-1) -> d_out (<=3)
+// Material net: head (<= 12 quads of slots) + 256 features -> 256 x (n-1) -> d_out (<=3)
 struct RenderNetDev {
     const void* blob;
     uint32_t blob_bytes;
@@ -73,6 +73,11 @@ struct RenderNetDev {
     int n_src;
     int src_kind[3];          // 0 points, 1 view_dirs, 2 normals
     int src_levels[3];
+    // skip connection at hidden layer `skip_layer` (models/fields.py:222-223: x = cat([x, rendering_input]) / sqrt(2)),
+    // -1 = none.  Its weights are stored as hidden block (x part), head block (w_head_skip) and a second hidden block
+    // (feature part); the hidden blocks stay one contiguous stream [.., skip x, skip features, ..].
+    int skip_layer;
+    uint32_t w_head_skip;
     int squeeze_out;
     float squeeze_out_scale, output_bias, output_scale;
 };

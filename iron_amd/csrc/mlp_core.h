@@ -110,15 +110,26 @@ template <int NQ>
 __device__ __forceinline__ void dense_head_pair(const WStream& ws, uint32_t base, int pair, const float* head,
                                                 f32x16& acc0, f32x16& acc1) {
     const uint32_t o = base + (uint32_t)pair * (NQ * 2048u);
-    f32x4 a0[NQ], a1[NQ];
+    // fragments are fetched in chunks of <= 6 quads (a 12-quad head -- the stage-1 colour net's PE-10 + PE-4 + normal
+    // inputs -- would otherwise hold 96 VGPRs of weights at once)
+    constexpr int kChunk = NQ <= 6 ? NQ : 6;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        a0[q] = ws.frag(o + q * 2048u);
-        a1[q] = ws.frag(o + q * 2048u + 1024u);
+    for (int q0 = 0; q0 < NQ; q0 += kChunk) {
+        f32x4 a0[kChunk], a1[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < NQ) {
+                a0[q] = ws.frag(o + (q0 + q) * 2048u);
+                a1[q] = ws.frag(o + (q0 + q) * 2048u + 1024u);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q0 + q < NQ)
+                mfma_quad(a0[q], a1[q], head[4 * (q0 + q)], head[4 * (q0 + q) + 1], head[4 * (q0 + q) + 2], head[4 * (q0 + q) + 3],
+                          acc0, acc1);
+        }
     }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-        mfma_quad(a0[q], a1[q], head[4 * q], head[4 * q + 1], head[4 * q + 2], head[4 * q + 3], acc0, acc1);
 }
 
 // Weight FIFO over one 256x256 layer: 128 steps of (two 1-KiB fragments -> 8 MFMAs), in the packed
@@ -203,6 +214,22 @@ __device__ __forceinline__ void hidden_layer(const WStream& ws, uint32_t w_base,
         f32x16 a0 = load_half_tile(ws, b_base, 2 * P);                                \
         f32x16 a1 = load_half_tile(ws, b_base, 2 * P + 1);                            \
         if (with_head) dense_head_pair<NQ>(ws, head_base, P, head, a0, a1);           \
+        dense_hidden_pair<P>(ws, w_base, wq, in, a0, a1);                             \
+        out[2 * P] = act(a0);                                                         \
+        out[2 * P + 1] = act(a1);                                                     \
+    }
+    IRON_PAIR(0) IRON_PAIR(1) IRON_PAIR(2) IRON_PAIR(3)
+#undef IRON_PAIR
+}
+
+// second half of a skip layer: out (the pre-activation partial sums of the first pass) += W * in, then the activation
+template <class Act>
+__device__ __forceinline__ void hidden_layer_accumulate(const WStream& ws, uint32_t w_base, WQueue& wq,
+                                                        const f32x16 (&in)[kHidTiles], f32x16 (&out)[kHidTiles], Act act) {
+#define IRON_PAIR(P)                                                                  \
+    {                                                                                 \
+        f32x16 a0 = out[2 * P];                                                       \
+        f32x16 a1 = out[2 * P + 1];                                                   \
         dense_hidden_pair<P>(ws, w_base, wq, in, a0, a1);                             \
         out[2 * P] = act(a0);                                                         \
         out[2 * P + 1] = act(a1);                                                     \

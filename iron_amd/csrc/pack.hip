@@ -188,7 +188,9 @@ int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
     Blob b;
     b.take(16);  // offset 0 is reserved as "absent"
     const size_t o_pe0 = b.take((size_t)kPairs * nq * 2 * 64);
-    const size_t o_hid = b.take((size_t)(nl - 2) * kF4PerHidLayer);
+    const int n_hid_blocks = (nl - 2) + (skip != -1 ? 1 : 0);
+    const size_t o_head_skip = skip != -1 ? b.take((size_t)kPairs * nq * 2 * 64) : 0;
+    const size_t o_hid = b.take((size_t)n_hid_blocks * kF4PerHidLayer);
     const size_t o_pes = b.take((size_t)kPairs * nq * 2 * 64);
     const size_t o_bias = b.take((size_t)(nl - 1) * kF4PerBiasLayer);
     const size_t o_last = b.take(kF4PerBiasLayer);
@@ -260,7 +262,10 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     const iron_net_desc& d = net->desc;
     const int nl = d.n_linear;
     if (d.d_hidden != kHidden || d.d_feature != kHidden || nl < 2 || nl > 17) return IRON_ERR_UNSUPPORTED;
-    if (d.skip_layer != -1) return IRON_ERR_UNSUPPORTED;  // upstream 8-layer skip variant: not built yet
+    // a skip connection is supported at a hidden layer (the stage-1 colour net: 8 layers, skip_in = [4]); the reference
+    // also builds 4-layer nets with skip_in = (4,), i.e. at the OUTPUT layer: not built
+    const int skip = d.skip_layer;
+    if (!(skip == -1 || (skip >= 1 && skip <= nl - 2))) return IRON_ERR_UNSUPPORTED;
     if (d.d_out < 1 || d.d_out > 3) return IRON_ERR_UNSUPPORTED;
 
     RenderNetDev& r = net->rnd;
@@ -287,18 +292,21 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     r.n_src = hs.n;
     const int head_w = col;
     int nq;
-    if (slot <= 20) nq = 5; else if (slot <= 24) nq = 6; else return IRON_ERR_UNSUPPORTED;
+    if (slot <= 20) nq = 5; else if (slot <= 24) nq = 6; else if (slot <= 48) nq = (slot + 3) / 4; else return IRON_ERR_UNSUPPORTED;
     for (int l = 0; l < nl; ++l) {
         if (!L[l].weight_v || !L[l].bias) return IRON_ERR_BAD_ARG;
-        const int want_in = (l == 0) ? head_w + d.d_feature : kHidden;
+        const int want_in = (l == 0) ? head_w + d.d_feature : (l == skip ? kHidden + head_w + d.d_feature : kHidden);
         const int want_out = (l == nl - 1) ? d.d_out : kHidden;
         if (L[l].in_dim != want_in || L[l].out_dim != want_out) return IRON_ERR_UNSUPPORTED;
     }
     Blob b;
     b.take(16);
     const size_t o_head = b.take((size_t)kPairs * nq * 2 * 64);
+    const size_t o_head_skip = skip != -1 ? b.take((size_t)kPairs * nq * 2 * 64) : 0;
+    // the feature block of layer 0 and the hidden blocks form ONE contiguous stream (the kernel's weight FIFO runs through)
     const size_t o_feat0 = b.take(kF4PerHidLayer);
-    const size_t o_hid = b.take((size_t)(nl - 2) * kF4PerHidLayer);
+    const int n_hid_blocks = (nl - 2) + (skip != -1 ? 1 : 0);
+    const size_t o_hid = b.take((size_t)n_hid_blocks * kF4PerHidLayer);
     const size_t o_bias = b.take((size_t)(nl - 1) * kF4PerBiasLayer);
     const size_t o_last = b.take(3 * kF4PerBiasLayer);
     size_t n_scale = 0;
@@ -316,9 +324,18 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     launch_pack_head(base + o_head, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, nq, st);
     launch_pack_hidden(base + o_feat0, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), head_w, kHidden, st);
     launch_pack_bias(base + o_bias, L[0].bias, 0, kHidden, st);
-    for (int l = 1; l <= nl - 2; ++l) {
-        launch_pack_hidden(base + o_hid + (size_t)(l - 1) * kF4PerHidLayer,
-                           make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), 0, kHidden, st);
+    for (int l = 1, blk = 0; l <= nl - 2; ++l) {
+        if (l == skip) {  // [x | head inputs | features] / sqrt(2): x block, head block, feature block
+            const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], kHidden, 0, kInvSqrt2);
+            launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer, ps, 0, kHidden, st);
+            HeadSrcs hs2 = hs;
+            for (int k = 0; k < hs2.n; ++k) hs2.col_off[k] += kHidden;
+            launch_pack_head(base + o_head_skip, ps, hs2, nq, st);
+            launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer, ps, kHidden + head_w, kHidden, st);
+        } else {
+            launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer,
+                               make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), 0, kHidden, st);
+        }
         launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, kHidden, st);
     }
     const iron_linear& last = L[nl - 1];
@@ -341,6 +358,8 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     r.d_out = d.d_out;
     r.n_hidden_layers = nl - 1;
     r.head_quads = nq;
+    r.skip_layer = skip;
+    r.w_head_skip = (uint32_t)(o_head_skip * 16);
     r.squeeze_out = d.squeeze_out;
     r.squeeze_out_scale = d.squeeze_out_scale;
     r.output_bias = d.output_bias;

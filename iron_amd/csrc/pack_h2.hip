@@ -166,6 +166,11 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
                     int head_w, hipStream_t st) {
     const iron_net_desc& d = net->desc;
     const int nl = d.n_linear;
+    // the h2 material kernels are built for skip-free nets whose head fits three 16-deep k-steps (24 slots); anything
+    // else (the stage-1 colour net: 48 head slots, skip at layer 4) keeps only its fp32 pack
+    int head_slots_total = 0;
+    for (int k = 0; k < hs.n; ++k) head_slots_total += head_slots(hs.levels[k]);
+    if (d.skip_layer != -1 || head_slots_total > kHeadSlots) return IRON_OK;
     std::vector<uint32_t> table;
     size_t off = 0;
     auto add = [&](int kind) { table.push_back((uint32_t)off); table.push_back((uint32_t)kind); off += kind ? kSlotBytes : 8192; };

@@ -407,14 +407,39 @@ struct MatArgs {
 };
 
 // LP: PE levels on points, LV: PE levels on view dirs (HAS_VIEW), HAS_NRM: normals present
+// the 256 features of this lane's point as register tiles (B-operand layout), from the packed per-tile buffer the
+// gradient kernel writes or from row-major rows
+__device__ __forceinline__ void load_feature_tiles(const MatArgs& a, int tile, int ai, bool ok, int lane, int half,
+                                                   f32x16 (&h)[kHidTiles]) {
+    if (a.feat_packed) {
+        const float* src = a.feat_packed + (size_t)tile * kSBufFloats;
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[t][r] = src[(t * 16 + r) * 64 + lane];
+    } else {
+        const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // features 32t + 8q + 4*half + 0..3 are contiguous
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = row[(32 * t + 8 * q + 4 * half) >> 2];
+                h[t][4 * q] = v.x; h[t][4 * q + 1] = v.y; h[t][4 * q + 2] = v.z; h[t][4 * q + 3] = v.w;
+            }
+    }
+}
+
 template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
 struct HeadCfg {
     static constexpr int kSlots = head_slots(LP) + (HAS_VIEW ? head_slots(LV) : 0) + (HAS_NRM ? 2 : 0);
-    static constexpr int kQuads = kSlots <= 20 ? 5 : 6;
-    static_assert(kSlots <= 24, "head too wide");
+    static constexpr int kQuads = kSlots <= 20 ? 5 : (kSlots <= 24 ? 6 : (kSlots + 3) / 4);  // as create_render picks nq
+    static_assert(kSlots <= 48, "head too wide");
 };
 
-template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
+// HAS_SKIP: the net has a skip connection at a hidden layer (compiled in only for the instance that needs it: the extra
+// layer variants in the runtime layer loop cost the skip-free instances ~250 spilled VGPRs otherwise)
+template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM, bool HAS_SKIP = false>
 __global__ __launch_bounds__(64, 1) void k_material(RenderNetDev net, MatArgs a) {
     using Cfg = HeadCfg<LP, LV, HAS_VIEW, HAS_NRM>;
     constexpr int NQ = Cfg::kQuads;
@@ -451,32 +476,27 @@ __global__ __launch_bounds__(64, 1) void k_material(RenderNetDev net, MatArgs a)
 
         // features -> register tiles (B-operand layout)
         f32x16 h[kHidTiles];
-        if (a.feat_packed) {
-            const float* src = a.feat_packed + (size_t)tile * kSBufFloats;
-#pragma unroll
-            for (int t = 0; t < kHidTiles; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[t][r] = src[(t * 16 + r) * 64 + lane];
-        } else {
-            const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
-#pragma unroll
-            for (int t = 0; t < kHidTiles; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {  // features 32t + 8q + 4*half + 0..3 are contiguous
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) v = row[(32 * t + 8 * q + 4 * half) >> 2];
-                    h[t][4 * q] = v.x; h[t][4 * q + 1] = v.y; h[t][4 * q + 2] = v.z; h[t][4 * q + 3] = v.w;
-                }
-        }
+        load_feature_tiles(a, tile, ai, ok, lane, half, h);
 
         // layer 0 (head + features) and the hidden layers share one linear weight stream
         WQueue wq;
         wq.prime(ws, net.w_feat0);
-        for (int l = 0; l < net.n_hidden_layers; ++l) {
-            const uint32_t wb = (l == 0) ? net.w_feat0 : net.w_hid + (uint32_t)(l - 1) * (kF4PerHidLayer * 16u);
+        for (int l = 0, blk = 0; l < net.n_hidden_layers; ++l) {
             const uint32_t bb = net.bias + (uint32_t)l * (kF4PerBiasLayer * 16u);
             f32x16 o[kHidTiles];
-            hidden_layer<ReluAct, NQ>(ws, wb, bb, l == 0, net.w_head0, head, wq, h, o, ReluAct());
+            if (l == 0) {
+                hidden_layer<ReluAct, NQ>(ws, net.w_feat0, bb, true, net.w_head0, head, wq, h, o, ReluAct());
+            } else if (HAS_SKIP && l == net.skip_layer) {
+                // x = cat([x, rendering_input]) / sqrt(2) (fields.py:222-223), the 1/sqrt(2) folded into the weights:
+                // first the x and head columns into the pre-activation sums, then the features (read again) on top
+                hidden_layer<IdentityAct, NQ>(ws, net.w_hid + (uint32_t)(blk++) * (kF4PerHidLayer * 16u), bb, true, net.w_head_skip, head,
+                                              wq, h, o, IdentityAct());
+                load_feature_tiles(a, tile, ai, ok, lane, half, h);
+                hidden_layer_accumulate<ReluAct>(ws, net.w_hid + (uint32_t)(blk++) * (kF4PerHidLayer * 16u), wq, h, o, ReluAct());
+            } else {
+                hidden_layer<ReluAct, NQ>(ws, net.w_hid + (uint32_t)(blk++) * (kF4PerHidLayer * 16u), bb, false, net.w_head0, head, wq, h, o,
+                                          ReluAct());
+            }
 #pragma unroll
             for (int t = 0; t < kHidTiles; ++t) h[t] = o[t];
         }
@@ -797,12 +817,15 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
         IRON_HIP_TRY(hipGetLastError());
         return IRON_OK;
     }
+    if (r.skip_layer != -1 && !(d.mode == IRON_MODE_IDR && lp == 10 && lv == 4)) return IRON_ERR_UNSUPPORTED;
     if (d.mode == IRON_MODE_IDR && lp == 0 && lv == 4) {
         hipLaunchKernelGGL((k_material<0, 4, true, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else if (d.mode == IRON_MODE_NO_VIEW_DIR && lp == 6) {
         hipLaunchKernelGGL((k_material<6, 0, false, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else if (d.mode == IRON_MODE_POINTS_ONLY && lp == 6) {
         hipLaunchKernelGGL((k_material<6, 0, false, false>), dim3(grid), dim3(64), 0, st, r, a);
+    } else if (d.mode == IRON_MODE_IDR && lp == 10 && lv == 4) {  // the stage-1 colour net (confs/womask_iron.conf)
+        hipLaunchKernelGGL((k_material<10, 4, true, true, true>), dim3(grid), dim3(64), 0, st, r, a);
     } else {
         return IRON_ERR_UNSUPPORTED;
     }

@@ -68,6 +68,14 @@ def main():
     with torch.no_grad():
         alpha, rgb = nets["nerf"](p4, vd)
     g.update({"nerf_pts": npf(p4), "nerf_views": npf(vd), "nerf_alpha": npf(alpha), "nerf_rgb": npf(rgb)})
+    # the colour net on its own (8 layers, PE-10 points, PE-4 views, skip at layer 4; models/fields.py:203-239)
+    cp = torch.rand(160, 3, generator=gen) * 1.2 - 0.6
+    cn = torch.randn(160, 3, generator=gen)
+    cv = torch.nn.functional.normalize(torch.randn(160, 3, generator=gen), dim=-1)
+    cf = torch.randn(160, 256, generator=gen) * 0.3
+    with torch.no_grad():
+        cout = nets["color_network"](cp, cn, cv, cf)
+    g.update({"color_pts": npf(cp), "color_nrm": npf(cn), "color_view": npf(cv), "color_feat": npf(cf), "color_out": npf(cout)})
     bins = torch.sort(torch.rand(16, 65, generator=gen), dim=-1)[0]
     w = torch.rand(16, 64, generator=gen) ** 4
     g.update({"pdf_bins": npf(bins), "pdf_weights": npf(w), "pdf_samples": npf(sample_pdf(bins, w, 16, det=True))})

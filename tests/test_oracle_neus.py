@@ -35,6 +35,9 @@ def test_g13_nerf_forward_and_sample_pdf():
     alpha, rgb = N.nerf_forward(cpu_sd(nets["nerf"]), N.NerfSpec(), t(g["nerf_pts"]), t(g["nerf_views"]))
     np.testing.assert_allclose(alpha.numpy(), g["nerf_alpha"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rgb.numpy(), g["nerf_rgb"], rtol=1e-5, atol=1e-6)
+    c = R.rendering_forward(cpu_sd(nets["color_network"]), N.COLOR_SPEC, t(g["color_pts"]), t(g["color_nrm"]), t(g["color_view"]),
+                            t(g["color_feat"]))
+    np.testing.assert_allclose(c.numpy(), g["color_out"], rtol=1e-5, atol=1e-6)
     s = N.sample_pdf(t(g["pdf_bins"]), t(g["pdf_weights"]), 16, det=True)
     np.testing.assert_allclose(s.numpy(), g["pdf_samples"], rtol=1e-6, atol=1e-7)
 
