@@ -62,11 +62,11 @@ typedef struct iron_linear {
     int32_t in_dim;
 } iron_linear;
 
-enum { IRON_NET_SDF = 0, IRON_NET_RENDER = 1 };
+enum { IRON_NET_SDF = 0, IRON_NET_RENDER = 1, IRON_NET_NERF = 2 };
 enum { IRON_MODE_IDR = 0, IRON_MODE_NO_VIEW_DIR = 1, IRON_MODE_NO_NORMAL = 2, IRON_MODE_POINTS_ONLY = 3 };
 
 typedef struct iron_net_desc {
-    int32_t kind;          /* IRON_NET_SDF | IRON_NET_RENDER                                        */
+    int32_t kind;          /* IRON_NET_SDF | IRON_NET_RENDER | IRON_NET_NERF                        */
     int32_t n_linear;      /* number of linear layers (= n_layers + 1)                              */
     int32_t d_hidden;      /* hidden width (256)                                                    */
     int32_t d_out;         /* SDF: 257 (sdf + feature); RENDER: 1..3                                */
@@ -104,6 +104,14 @@ int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sd
  * not read it.  out [n,d_out]. */
 int iron_render_forward(const iron_net_t* net, const float* points, const float* normals,
                         const float* view_dirs, const float* features, int64_t n, float* out, void* stream);
+
+/* NeRF.forward (models/fields.py:299-327, use_viewdirs=True): pts [n,4] (the stage-1 background
+ * parametrisation (x/r, 1/r)), view_dirs [n,3] -> alpha [n] (raw density), rgb [n,3] (raw).  The net is created with
+ * kind IRON_NET_NERF, d_hidden 256, multires / multires_view = PE levels, skip_layer = the layer after which the input is
+ * concatenated again (4), n_linear = D + 4 layers in the order pts_linears[0..D-1], alpha_linear, feature_linear,
+ * views_linears[0], rgb_linear (plain nn.Linear: weight_g = NULL). */
+int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, const float* view_dirs, int64_t n, float* alpha, float* rgb,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise geometry

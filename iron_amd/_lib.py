@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libiron_hip.so")
 
 IRON_OK = 0
+IRON_NET_NERF = 2
 IRON_ERR_UNSUPPORTED = -2
 IRON_NET_SDF, IRON_NET_RENDER = 0, 1
 MODES = {"idr": 0, "no_view_dir": 1, "no_normal": 2, "points_only": 3}
@@ -88,6 +89,7 @@ SYMBOLS = {
     "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "iron_composite_colocated": (C.c_int, [C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "iron_coloc_head": (C.c_int, [_I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_nerf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "iron_edge_walk": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _P, _P, _P]),
     "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "iron_sobel_magnitude": (C.c_int, [_P, _I32, _I32, _P, _P]),

@@ -82,6 +82,25 @@ struct RenderNetDev {
     float squeeze_out_scale, output_bias, output_scale;
 };
 
+// NeRF background field (models/fields.py:243-327, use_viewdirs=True): 4-D points with PE-L (head of 2 + 4 L slots:
+// (x|y), (z|w), then per (level, component) one (sin|cos) slot), D relu layers of 256 with the input concatenated again
+// in front of layer skip+1, alpha row, a linear feature layer, [feature, PE(view)] -> 128 relu, 3 rgb rows.
+struct NerfNetDev {
+    const void* blob;
+    uint32_t blob_bytes;
+    uint32_t w_head0;      // layer 0 on the point head            [pairs][NQ4][2][64]
+    uint32_t w_head_skip;  // layer skip+1, point-head columns     [pairs][NQ4][2][64]
+    uint32_t w_hid;        // layers 1..D-1, feature layer, view layer (rows 0..127): contiguous hidden blocks
+    uint32_t w_head_view;  // view layer, PE(view) columns         [pairs][NQV][2][64]
+    uint32_t bias;         // layers 0..D-1, feature, view         [D+2][8][2][4]
+    uint32_t w_alpha;      // alpha row                            [8][2][4]
+    uint32_t w_rgb;        // rgb rows over the 128 view features  [3][8][2][4]
+    float b_alpha, b_rgb[3];
+    int n_layers;          // D
+    int skip_after;        // index i with h = cat([x, h]) after layer i (4); -1 none
+    int levels, levels_view;
+};
+
 // Packed weight stream of the h2 core (mlp_h2.h): the slot sequence the LDS ring walks.
 struct H2StreamDev {
     const char* base;     // packed stream (global)
@@ -101,6 +120,7 @@ struct iron_net {
     size_t blob_bytes;
     iron::SdfNetDev sdf;
     iron::RenderNetDev rnd;
+    iron::NerfNetDev nerf;
     void* h2_blob;        // h2 (split-fp16) stream, SDF nets
     iron::H2StreamDev h2_trace;  // hidden stack only
     iron::H2StreamDev h2_full;   // + the feature rows of the last layer

@@ -93,6 +93,24 @@ __device__ __forceinline__ void head_fill(float vx, float vy, float vz, int half
     }
 }
 
+// 4-component source (NeRF background points): slot0 = (x|y), slot1 = (z|w), then (sin|cos)(2^k v_c) at 2 + 4k + c
+template <int LEVELS>
+__device__ __forceinline__ void head_fill4(float vx, float vy, float vz, float vw, int half, float* slots) {
+    slots[0] = half ? vy : vx;
+    slots[1] = half ? vw : vz;
+    const float v[4] = {vx, vy, vz, vw};
+#pragma unroll
+    for (int k = 0; k < LEVELS; ++k) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float s, cs;
+            sincosf(v[c] * f, &s, &cs);
+            slots[2 + 4 * k + c] = half ? cs : s;
+        }
+    }
+}
+
 __device__ __forceinline__ void mfma_quad(const f32x4& a0, const f32x4& a1, float b0, float b1, float b2, float b3,
                                           f32x16& acc0, f32x16& acc1) {
     acc0 = mfma32(a0.x, b0, acc0);
@@ -201,16 +219,31 @@ __device__ __forceinline__ float row_dot(const WStream& ws, uint32_t base, const
     return s + __shfl_xor(s, 32, 64);
 }
 
+// the same over the first NT tiles only (a layer narrower than 256)
+template <int NT>
+__device__ __forceinline__ float row_dot_n(const WStream& ws, uint32_t base, const f32x16 (&h)[kHidTiles]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x16 w = load_half_tile(ws, base, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s = fmaf(w[r], h[t][r], s);
+    }
+    return s + __shfl_xor(s, 32, 64);
+}
+
 constexpr int kSdfPeLevels = 6;
 constexpr int kSdfHeadQuads = head_slots(kSdfPeLevels) / 4;  // 20 slots -> 5 quads
 
 // one 256 -> 256 layer (+ optional head product), activation ACT applied, result in `out`
-template <class Act, int NQ>
+// NPAIRS < 4: only the first 64 * NPAIRS output features exist (NeRF's 128-wide view layer); the weight FIFO still walks
+// the block linearly, so such a layer must be the LAST consumer of the stream.
+template <class Act, int NQ, int NPAIRS = kPairs>
 __device__ __forceinline__ void hidden_layer(const WStream& ws, uint32_t w_base, uint32_t b_base, bool with_head,
                                              uint32_t head_base, const float* head, WQueue& wq,
                                              const f32x16 (&in)[kHidTiles], f32x16 (&out)[kHidTiles], Act act) {
 #define IRON_PAIR(P)                                                                  \
-    {                                                                                 \
+    if constexpr (P < NPAIRS) {                                                       \
         f32x16 a0 = load_half_tile(ws, b_base, 2 * P);                                \
         f32x16 a1 = load_half_tile(ws, b_base, 2 * P + 1);                            \
         if (with_head) dense_head_pair<NQ>(ws, head_base, P, head, a0, a1);           \

@@ -82,6 +82,33 @@ __global__ void k_pack_head(float4* __restrict__ dst, PackSrc s, HeadSrcs hs, in
     dst[e] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// The same for ONE 4-component source with `levels` PE levels (NeRF background points; slot layout of head_fill4):
+// reference column order (models/embedder.py:27-36) [v(4), sin(2^0 v)(4), cos(2^0 v)(4), ...]
+__global__ void k_pack_head4(float4* __restrict__ dst, PackSrc s, int levels, int col_off, int nq) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPairs * nq * 2 * 64) return;
+    const int lane = e & 63;
+    const int w = (e >> 6) & 1;
+    const int q = (e >> 7) % nq;
+    const int p = (e >> 7) / nq;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * (2 * p + w) + i;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int slot = 4 * q + c;
+        int col = -1;
+        if (slot == 0) col = h;
+        else if (slot == 1) col = 2 + h;
+        else if (slot < 2 + 4 * levels) col = 4 + 8 * ((slot - 2) / 4) + 4 * h + ((slot - 2) % 4);
+        float x = 0.0f;
+        if (col >= 0 && row < s.rows_valid)
+            x = s.w[(size_t)(s.row_off + row) * s.ld + col_off + col] * s.scale[s.row_off + row] * s.mul;
+        v[c] = x;
+    }
+    dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // dst [8][2][16] floats: element (tile, h, r) = bias[row_off + 32*tile + (r&3) + 8*(r>>2) + 4*h]
 __global__ void k_pack_bias(float* __restrict__ dst, const float* __restrict__ bias, int row_off, int rows_valid) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +394,107 @@ int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
     return build_h2_render(net, L, scale_base, soff, hs, head_w, st);
 }
 
+// NeRF background field (models/fields.py:243-297).  layers: pts_linears[0..D-1], alpha_linear, feature_linear,
+// views_linears[0], rgb_linear.
+int create_nerf(iron_net* net, const iron_linear* L, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int D = d.n_linear - 4;
+    const int lp = d.multires > 0 ? d.multires : 0, lv = d.multires_view > 0 ? d.multires_view : 0;
+    const int skip = d.skip_layer;  // h = cat([x, h]) after layer `skip`
+    if (d.d_hidden != kHidden || D < 2 || D > 14 || lp < 1 || lp > 10) return IRON_ERR_UNSUPPORTED;
+    if (!(skip == -1 || (skip >= 0 && skip <= D - 2))) return IRON_ERR_UNSUPPORTED;
+    const int in_p = 4 + 8 * lp, in_v = pe_width(lv);
+    const int nq4 = (2 + 4 * lp + 3) / 4, nqv = (head_slots(lv) + 3) / 4;
+    if (nq4 > 12 || nqv > 12) return IRON_ERR_UNSUPPORTED;
+    for (int l = 0; l < d.n_linear; ++l) {
+        if (!L[l].weight_v || !L[l].bias) return IRON_ERR_BAD_ARG;
+        int want_in = kHidden, want_out = kHidden;
+        if (l == 0) want_in = in_p;
+        else if (l < D && l == skip + 1 && skip != -1) want_in = kHidden + in_p;
+        if (l == D) want_out = 1;                                   // alpha_linear
+        if (l == D + 2) { want_in = in_v + kHidden; want_out = kHidden / 2; }  // views_linears[0]
+        if (l == D + 3) { want_in = kHidden / 2; want_out = 3; }    // rgb_linear
+        if (L[l].in_dim != want_in || L[l].out_dim != want_out) return IRON_ERR_UNSUPPORTED;
+    }
+    NerfNetDev& r = net->nerf;
+    memset(&r, 0, sizeof(r));
+    Blob b;
+    b.take(16);
+    const size_t o_head0 = b.take((size_t)kPairs * nq4 * 2 * 64);
+    const size_t o_head_skip = b.take((size_t)kPairs * nq4 * 2 * 64);
+    const size_t o_head_view = b.take((size_t)kPairs * nqv * 2 * 64);
+    const int n_blocks = (D - 1) + 2;  // hidden layers 1..D-1, feature layer, view layer
+    const size_t o_hid = b.take((size_t)n_blocks * kF4PerHidLayer + kF4PerHidLayer / 8);  // + slack for the FIFO's look-ahead
+    const size_t o_bias = b.take((size_t)(D + 2) * kF4PerBiasLayer);
+    const size_t o_alpha = b.take(kF4PerBiasLayer);
+    const size_t o_rgb = b.take(3 * kF4PerBiasLayer);
+    size_t n_scale = 0;
+    for (int l = 0; l < d.n_linear; ++l) n_scale += (size_t)L[l].out_dim;
+    const size_t o_scale = b.take((n_scale + 3) / 4);
+    net->blob_bytes = b.n_f4 * sizeof(float4);
+    IRON_HIP_TRY(hipMalloc(&net->blob, net->blob_bytes));
+    IRON_HIP_TRY(hipMemsetAsync(net->blob, 0, net->blob_bytes, st));
+    float4* base = (float4*)net->blob;
+    float* scale_base = (float*)(base + o_scale);
+    size_t soff[32];
+    int rc = fold_scales(L, d.n_linear, scale_base, soff, st);  // plain nn.Linear: weight_g == NULL -> scale 1
+    if (rc != IRON_OK) return rc;
+    auto head4 = [&](size_t dst, const iron_linear& lin, const float* sc, int col_off) {
+        const int n = kPairs * nq4 * 2 * 64;
+        hipLaunchKernelGGL(k_pack_head4, dim3((n + 255) / 256), dim3(256), 0, st, base + dst, make_pack_src(lin, sc, kHidden, 0, 1.0f), lp,
+                           col_off, nq4);
+    };
+    head4(o_head0, L[0], scale_base + soff[0], 0);
+    launch_pack_bias(base + o_bias, L[0].bias, 0, kHidden, st);
+    int blk = 0;
+    for (int l = 1; l < D; ++l) {
+        const bool skip_in = (skip != -1 && l == skip + 1);  // input = [x (in_p) | h (256)]
+        if (skip_in) head4(o_head_skip, L[l], scale_base + soff[l], 0);
+        launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer, make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f),
+                           skip_in ? in_p : 0, kHidden, st);
+        launch_pack_bias(base + o_bias + (size_t)l * kF4PerBiasLayer, L[l].bias, 0, kHidden, st);
+    }
+    // feature_linear (no activation)
+    launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer, make_pack_src(L[D + 1], scale_base + soff[D + 1], kHidden, 0, 1.0f), 0,
+                       kHidden, st);
+    launch_pack_bias(base + o_bias + (size_t)D * kF4PerBiasLayer, L[D + 1].bias, 0, kHidden, st);
+    // views_linears[0]: input = [feature (256) | PE(view)], 128 outputs (rows 128..255 of the block stay zero)
+    launch_pack_hidden(base + o_hid + (size_t)(blk++) * kF4PerHidLayer, make_pack_src(L[D + 2], scale_base + soff[D + 2], kHidden / 2, 0, 1.0f),
+                       0, kHidden, st);
+    {
+        HeadSrcs hv;
+        memset(&hv, 0, sizeof(hv));
+        hv.n = 1; hv.slot_base[0] = 0; hv.levels[0] = lv; hv.col_off[0] = kHidden;
+        launch_pack_head(base + o_head_view, make_pack_src(L[D + 2], scale_base + soff[D + 2], kHidden / 2, 0, 1.0f), hv, nqv, st);
+    }
+    launch_pack_bias(base + o_bias + (size_t)(D + 1) * kF4PerBiasLayer, L[D + 2].bias, 0, kHidden / 2, st);
+    launch_pack_row(base + o_alpha, make_pack_src(L[D], scale_base + soff[D], 1, 0, 1.0f), 0, 0, kHidden, st);
+    for (int o = 0; o < 3; ++o)
+        launch_pack_row(base + o_rgb + (size_t)o * kF4PerBiasLayer, make_pack_src(L[D + 3], scale_base + soff[D + 3], 3, 0, 1.0f), o, 0,
+                        kHidden / 2, st);
+    IRON_HIP_TRY(hipGetLastError());
+    float ba = 0.f, brgb[3] = {0, 0, 0};
+    IRON_HIP_TRY(hipMemcpyAsync(&ba, L[D].bias, sizeof(float), hipMemcpyDeviceToHost, st));
+    IRON_HIP_TRY(hipMemcpyAsync(brgb, L[D + 3].bias, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+    r.blob = net->blob;
+    r.blob_bytes = (uint32_t)net->blob_bytes;
+    r.w_head0 = (uint32_t)(o_head0 * 16);
+    r.w_head_skip = (uint32_t)(o_head_skip * 16);
+    r.w_hid = (uint32_t)(o_hid * 16);
+    r.w_head_view = (uint32_t)(o_head_view * 16);
+    r.bias = (uint32_t)(o_bias * 16);
+    r.w_alpha = (uint32_t)(o_alpha * 16);
+    r.w_rgb = (uint32_t)(o_rgb * 16);
+    r.b_alpha = ba;
+    for (int o = 0; o < 3; ++o) r.b_rgb[o] = brgb[o];
+    r.n_layers = D;
+    r.skip_after = skip;
+    r.levels = lp;
+    r.levels_view = lv;
+    return IRON_OK;
+}
+
 }  // namespace
 
 extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, const iron_linear* layers, void* stream) {
@@ -383,6 +511,7 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
     hipStream_t st = (hipStream_t)stream;
     if (desc->kind == IRON_NET_SDF) rc = create_sdf(net, layers, st);
     else if (desc->kind == IRON_NET_RENDER) rc = create_render(net, layers, st);
+    else if (desc->kind == IRON_NET_NERF) rc = create_nerf(net, layers, st);
     else rc = IRON_ERR_UNSUPPORTED;
     if (rc != IRON_OK) {
         if (net->blob) (void)hipFree(net->blob);

@@ -87,7 +87,7 @@ class _HipNet(nn.Module):
         arr = (_lib.iron_linear * len(layers))()
         keep = []
         for i, lin in enumerate(layers):
-            if lin.has_weight_norm:
+            if getattr(lin, "has_weight_norm", False):
                 v = lin.weight_v.detach().float().contiguous()
                 g = lin.weight_g.detach().float().contiguous().view(-1)
                 keep += [v, g]
@@ -291,3 +291,77 @@ class RenderingNetwork(_HipNet):
             _lib.check(_lib.load().iron_render_forward(net.handle, p.data_ptr(), _lib.ptr(nrm), _lib.ptr(vd),
                                                        ft.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(p.device)))
         return out.reshape(sh + [self.d_out])
+
+
+# NeRF background field of the stage-1 renderer (reference: models/fields.py:243-327)
+class NeRF(_HipNet):
+    """Same constructor, parameter names (pts_linears.N / views_linears.0 / feature_linear / alpha_linear / rgb_linear, plain
+    nn.Linear) and RNG consumption as the reference; forward runs on the HIP kernel `k_nerf` (iron_nerf_forward)."""
+
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        from .embedder import get_embedder
+        self.D, self.W, self.d_in, self.d_in_view = D, W, d_in, d_in_view
+        self.multires, self.multires_view = multires, multires_view
+        self.input_ch, self.input_ch_view = 3, 3
+        self.embed_fn = self.embed_fn_view = None
+        if multires > 0:
+            self.embed_fn, self.input_ch = get_embedder(multires, input_dims=d_in)
+        if multires_view > 0:
+            self.embed_fn_view, self.input_ch_view = get_embedder(multires_view, input_dims=d_in_view)
+        self.skips = list(skips)
+        self.use_viewdirs = use_viewdirs
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)]
+            + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def _layers(self):
+        return list(self.pts_linears) + [self.alpha_linear, self.feature_linear, self.views_linears[0], self.rgb_linear]
+
+    def _desc(self) -> _lib.iron_net_desc:
+        if not self.use_viewdirs:
+            raise NotImplementedError("NeRF(use_viewdirs=False): the reference's forward asserts False there (fields.py:326-327)")
+        if self.d_in != 4 or self.d_in_view != 3 or len(self.skips) > 1:
+            raise _lib.IronError("the HIP NeRF kernel is built for the stage-1 background field (d_in=4, d_in_view=3, one skip)")
+        d = _lib.iron_net_desc()
+        d.kind = _lib.IRON_NET_NERF
+        d.n_linear = self.D + 4
+        d.d_hidden = self.W
+        d.d_out = 4
+        d.multires, d.multires_view = self.multires, self.multires_view
+        d.skip_layer = self.skips[0] if self.skips else -1
+        d.scale = 1.0
+        return d
+
+    @torch.no_grad()
+    def forward(self, input_pts, input_views):
+        """[...,4], [...,3] -> (alpha [...,1], rgb [...,3])  (fields.py:299-325)."""
+        p = _lib.require_cuda_f32(input_pts.detach(), "input_pts")
+        sh = list(p.shape[:-1])
+        p = p.reshape(-1, 4)
+        v = _lib.require_cuda_f32(input_views.detach(), "input_views").reshape(-1, 3)
+        n = p.shape[0]
+        alpha = torch.empty(n, dtype=torch.float32, device=p.device)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.load().iron_nerf_forward(self.hip_net().handle, p.data_ptr(), v.data_ptr(), n, alpha.data_ptr(),
+                                                     rgb.data_ptr(), _lib.stream_ptr(p.device)))
+        return alpha.reshape(sh + [1]), rgb.reshape(sh + [3])
+
+
+class SingleVarianceNetwork(nn.Module):
+    """models/fields.py:415-421."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(init_val)))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)

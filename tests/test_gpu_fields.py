@@ -119,3 +119,27 @@ def test_stage1_colour_network_with_skip():
     for n in (1, 33):
         o2 = net(t(g["color_pts"]).cuda()[:n], t(g["color_nrm"]).cuda()[:n], t(g["color_view"]).cuda()[:n], t(g["color_feat"]).cuda()[:n])
         np.testing.assert_allclose(o2.cpu().numpy(), out[:n].cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_nerf_background_field():
+    """NeRF.forward (fields.py:299-325; the stage-1 background field: 4-D points PE-10, views PE-4, skip after layer 4,
+    alpha / feature / view / rgb heads) vs the reference (G13); constructor parity is part of the stage-1 state hash."""
+    from iron_amd.fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    from _util import golden_meta, state_hash
+    torch.manual_seed(0)
+    nets = {
+        "sdf_network": SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                                  geometric_init=True, weight_norm=True),
+        "color_network": RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=8, skip_in=[4],
+                                          weight_norm=True, multires=10, multires_view=4, squeeze_out=True),
+        "nerf": NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True),
+        "deviation_network": SingleVarianceNetwork(0.3),
+    }
+    assert state_hash(nets) == golden_meta()["state_sha256_stage1"]
+    g = golden("g13_neus.npz")
+    nerf = nets["nerf"].cuda()
+    alpha, rgb = nerf(t(g["nerf_pts"]).cuda(), t(g["nerf_views"]).cuda())
+    assert tuple(alpha.shape) == g["nerf_alpha"].shape and tuple(rgb.shape) == g["nerf_rgb"].shape
+    ra, rc = rel_l2(alpha.cpu().numpy(), g["nerf_alpha"]), rel_l2(rgb.cpu().numpy(), g["nerf_rgb"])
+    print("NeRF: alpha rel-L2 %.2e  rgb rel-L2 %.2e" % (ra, rc))
+    assert ra <= 1e-5 and rc <= 1e-5
