@@ -113,6 +113,49 @@ int iron_render_forward(const iron_net_t* net, const float* points, const float*
 int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, const float* view_dirs, int64_t n, float* alpha, float* rgb,
                       void* stream);
 
+/* Per-ray stages of NeuSRenderer.render (models/renderer.py:346-453; rows of at most 192 samples, one thread per ray):
+ *   iron_neus_linspace    z = near + (far - near) * linspace(0,1,m)                              (:357-358)
+ *   iron_neus_outside_z   z = far / rev[j] + offset: depths of the n_outside background samples            (:380-381)
+ *   iron_neus_points      pts = o + d * z                                                        (:389, :236)
+ *   iron_neus_up_sample   up_sample (:189-232) + sample_pdf(det=True) (:45-75): n_importance new depths per ray
+ *   iron_neus_merge       the sort of cat([z, new_z]) as a merge of two ascending rows, sdf carried along (:238-246)
+ *   iron_neus_mid_points  section lengths, mid points and per-sample dirs of render_core (:265-277); outside != 0: the
+ *                         (x/r, 1/r) parametrisation of render_core_outside (:163-172), pts [n*m,4]
+ *   iron_neus_composite   render_core's alpha (logistic CDF), inside-sphere blend with the NeRF background, weights,
+ *                         colour, weight_sum / weight_max, cdf, inside_sphere, eikonal statistics (:279-344, :174-178). */
+int iron_neus_linspace(const float* near, const float* far, const float* lin, int64_t n, int32_t m, float* z, void* stream);
+int iron_neus_outside_z(const float* far, const float* rev, int64_t n, int32_t m, float offset, float* z, void* stream);
+int iron_neus_points(const float* rays_o, const float* rays_d, const float* z, int64_t n, int32_t m, float* pts, void* stream);
+int iron_neus_up_sample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t n, int32_t m,
+                        int32_t n_importance, float inv_s, float* new_z, void* stream);
+int iron_neus_merge(const float* z_a, const float* s_a, int32_t m_a, const float* z_b, const float* s_b, int32_t m_b, int64_t n,
+                    float* z_out, float* s_out, void* stream);
+int iron_neus_mid_points(const float* rays_o, const float* rays_d, const float* z, int64_t n, int32_t m, float sample_dist,
+                         int32_t outside, float* dists, float* pts, float* dirs, void* stream);
+typedef struct iron_neus_composite_args {
+    const float* dists;            /* [n,m]   section lengths of the inside samples                      */
+    const float* pts;              /* [n*m,3] section mid points                                         */
+    const float* dirs;             /* [n*m,3]                                                            */
+    const float* sdf;              /* [n*m]                                                              */
+    const float* grad;             /* [n*m,3] d sdf / dx                                                 */
+    const float* color;            /* [n*m,3] colour network output                                      */
+    const float* bg_dists;         /* [n,mo]  outside pass (NULL: no background model)                   */
+    const float* bg_density;       /* [n*mo]  NeRF alpha output                                          */
+    const float* bg_color;         /* [n*mo,3] NeRF rgb output                                           */
+    const float* background_rgb;   /* [3] or NULL                                                        */
+    int64_t n;
+    int32_t m, mo;                 /* mo = m + n_outside when the background model is used               */
+    float inv_s, cos_anneal_ratio;
+    float* out_color;              /* [n,3]                                                              */
+    float* weights;                /* [n, mo or m]                                                       */
+    float* cdf;                    /* [n,m] or NULL                                                      */
+    float* inside_sphere;          /* [n,m] or NULL                                                      */
+    float* weight_sum;             /* [n]                                                                */
+    float* weight_max;             /* [n]                                                                */
+    float* gradient_error_acc;     /* [2]: sum(relax * (|g|-1)^2), sum(relax); or NULL                   */
+} iron_neus_composite_args;
+int iron_neus_composite(const iron_neus_composite_args* args, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pointwise geometry
  * ------------------------------------------------------------------------------------------- */

@@ -40,6 +40,14 @@ class iron_composite_params(C.Structure):
                                           "metallic_k", "dielectric_eta", "env_light")]
 
 
+class iron_neus_composite_args(C.Structure):
+    _fields_ = ([(k, C.c_void_p) for k in ("dists", "pts", "dirs", "sdf", "grad", "color", "bg_dists", "bg_density", "bg_color",
+                                           "background_rgb")]
+                + [("n", C.c_int64), ("m", C.c_int32), ("mo", C.c_int32), ("inv_s", C.c_float), ("cos_anneal_ratio", C.c_float)]
+                + [(k, C.c_void_p) for k in ("out_color", "weights", "cdf", "inside_sphere", "weight_sum", "weight_max",
+                                             "gradient_error_acc")])
+
+
 class iron_trace_params(C.Structure):
     _fields_ = [("sdf_threshold", C.c_float), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
                 ("chunk", C.c_int64)]
@@ -89,6 +97,13 @@ SYMBOLS = {
     "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "iron_composite_colocated": (C.c_int, [C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "iron_coloc_head": (C.c_int, [_I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_neus_linspace": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
+    "iron_neus_outside_z": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
+    "iron_neus_points": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
+    "iron_neus_up_sample": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P]),
+    "iron_neus_merge": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I64, _P, _P, _P]),
+    "iron_neus_mid_points": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P, _P, _P, _P]),
+    "iron_neus_composite": (C.c_int, [C.POINTER(iron_neus_composite_args), _P]),
     "iron_nerf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "iron_edge_walk": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _P, _P, _P]),
     "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),

@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libiron_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 
-SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "profile.hip"]
+SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "neus.hip", "profile.hip"]
 HEADERS = ["iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
 
 BASE_FLAGS = [

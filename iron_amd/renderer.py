@@ -1,0 +1,163 @@
+"""Stage-1 NeuS volume renderer on the HIP kernels -- mirror of `models/renderer.py:128-453`.
+
+`NeuSRenderer.render` keeps the reference's signature and output dictionary.  Every array stage runs as a HIP kernel
+behind the C ABI: sample placement, hierarchical up-sampling (inverse CDF), sorted merges and compositing are the
+per-ray kernels of csrc/neus.hip; the network evaluations between them are the batched SDF / colour / NeRF kernels the
+field classes of `iron_amd.fields` already front.  Forward only (no autograd graph): training is row f-2.
+There is no CPU path -- tensors must live on the GPU and the HIP library must load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    return _lib.require_cuda_f32(t.detach(), name).contiguous()
+
+
+class NeuSRenderer:
+    """models/renderer.py:128-149 (same constructor arguments, same attribute names)."""
+
+    def __init__(self, nerf, sdf_network, deviation_network, color_network, n_samples, n_importance, n_outside, up_sample_steps,
+                 perturb):
+        self.nerf = nerf
+        self.sdf_network = sdf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+
+    # ---- per-ray kernels -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _points(rays_o, rays_d, z):
+        n, m = z.shape
+        pts = torch.empty((n * m, 3), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().iron_neus_points(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), n, m, pts.data_ptr(),
+                                                _lib.stream_ptr(z.device)))
+        return pts
+
+    @staticmethod
+    def _merge(z_a, s_a, z_b, s_b):
+        n, ma = z_a.shape
+        mb = z_b.shape[1]
+        z = torch.empty((n, ma + mb), dtype=torch.float32, device=z_a.device)
+        s = torch.empty_like(z) if s_a is not None else None
+        _lib.check(_lib.load().iron_neus_merge(z_a.data_ptr(), _lib.ptr(s_a), ma, z_b.data_ptr(), _lib.ptr(s_b), mb, n, z.data_ptr(),
+                                               _lib.ptr(s), _lib.stream_ptr(z.device)))
+        return z, s
+
+    @staticmethod
+    def _mid_points(rays_o, rays_d, z, sample_dist, outside):
+        n, m = z.shape
+        dists = torch.empty_like(z)
+        pts = torch.empty((n * m, 4 if outside else 3), dtype=torch.float32, device=z.device)
+        dirs = torch.empty((n * m, 3), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().iron_neus_mid_points(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), n, m, float(sample_dist),
+                                                    int(outside), dists.data_ptr(), pts.data_ptr(), dirs.data_ptr(),
+                                                    _lib.stream_ptr(z.device)))
+        return dists, pts, dirs
+
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        """renderer.py:189-232: n_importance new depths per ray from the section weights at sharpness inv_s."""
+        rays_o, rays_d, z_vals, sdf = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z_vals, "z_vals"), _f32(sdf, "sdf")
+        n, m = z_vals.shape
+        new_z = torch.empty((n, n_importance), dtype=torch.float32, device=z_vals.device)
+        with torch.cuda.device(z_vals.device):
+            _lib.check(_lib.load().iron_neus_up_sample(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), sdf.data_ptr(), n, m,
+                                                       int(n_importance), float(inv_s), new_z.data_ptr(),
+                                                       _lib.stream_ptr(z_vals.device)))
+        return new_z
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, last=False):
+        """renderer.py:234-248: merge the new depths in; unless `last`, evaluate and carry their sdf along."""
+        rays_o, rays_d, z_vals, new_z_vals = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z_vals, "z_vals"), _f32(new_z_vals, "new_z")
+        with torch.cuda.device(z_vals.device):
+            if last:
+                z, _ = self._merge(z_vals, None, new_z_vals, None)
+                return z, sdf
+            new_sdf = self.sdf_network.sdf(self._points(rays_o, rays_d, new_z_vals)).reshape(new_z_vals.shape)
+            return self._merge(z_vals, _f32(sdf, "sdf"), new_z_vals, new_sdf)
+
+    # ---- render ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0) -> Dict[str, torch.Tensor]:
+        """renderer.py:346-453, perturb = 0 (the validation / deterministic path)."""
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        if perturb > 0:
+            raise NotImplementedError("iron_amd.NeuSRenderer renders the deterministic path (perturb = 0); stratified jitter "
+                                      "belongs to the training loop (SURVEY 8 row f-2)")
+        rays_o, rays_d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+        dev = rays_o.device
+        batch = rays_o.shape[0]
+        near = _f32(near, "near").reshape(-1).expand(batch).contiguous()
+        far = _f32(far, "far").reshape(-1).expand(batch).contiguous()
+        lib = _lib.load()
+        sample_dist = 2.0 / self.n_samples
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            lin = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
+            z_vals = torch.empty((batch, self.n_samples), dtype=torch.float32, device=dev)
+            _lib.check(lib.iron_neus_linspace(near.data_ptr(), far.data_ptr(), lin.data_ptr(), batch, self.n_samples, z_vals.data_ptr(), st))
+            n_samples = self.n_samples
+            if self.n_importance > 0:
+                sdf = self.sdf_network.sdf(self._points(rays_o, rays_d, z_vals)).reshape(batch, self.n_samples)
+                for i in range(self.up_sample_steps):
+                    new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, self.n_importance // self.up_sample_steps, 64 * 2 ** i)
+                    z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
+                n_samples = self.n_samples + self.n_importance
+
+            a = _lib.iron_neus_composite_args()
+            keep = []
+            if self.n_outside > 0:
+                # far / flip(linspace(1e-3, 1 - 1/(n_outside+1))) + 1/n_samples: one ascending row per ray (:361-381)
+                rev = torch.flip(torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev), dims=[-1]).contiguous()
+                z_out = torch.empty((batch, self.n_outside), dtype=torch.float32, device=dev)
+                _lib.check(lib.iron_neus_outside_z(far.data_ptr(), rev.data_ptr(), batch, self.n_outside, 1.0 / self.n_samples,
+                                                   z_out.data_ptr(), st))
+                z_feed, _ = self._merge(z_vals, None, z_out, None)
+                bg_dists, bg_pts, bg_dirs = self._mid_points(rays_o, rays_d, z_feed, sample_dist, True)
+                density, bg_color = self.nerf(bg_pts, bg_dirs)
+                density, bg_color = density.contiguous(), bg_color.contiguous()
+                keep += [bg_dists, density, bg_color]
+                a.bg_dists, a.bg_density, a.bg_color = bg_dists.data_ptr(), density.data_ptr(), bg_color.data_ptr()
+                a.mo = z_feed.shape[1]
+            dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, False)
+            sdf, feat, grad = self.sdf_network.get_all(pts, is_training=False)
+            color = self.color_network(pts, grad, dirs, feat).contiguous()
+            inv_s = float(self.deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6))
+            n_tot = a.mo if self.n_outside > 0 else n_samples
+            out_color = torch.empty((batch, 3), dtype=torch.float32, device=dev)
+            weights = torch.empty((batch, n_tot), dtype=torch.float32, device=dev)
+            cdf = torch.empty((batch, n_samples), dtype=torch.float32, device=dev)
+            inside = torch.empty((batch, n_samples), dtype=torch.float32, device=dev)
+            wsum = torch.empty((batch, 1), dtype=torch.float32, device=dev)
+            wmax = torch.empty((batch, 1), dtype=torch.float32, device=dev)
+            gacc = torch.zeros(2, dtype=torch.float32, device=dev)
+            bgc = _f32(background_rgb, "background_rgb").reshape(3) if background_rgb is not None else None
+            a.dists, a.pts, a.dirs, a.sdf, a.grad, a.color = (t.data_ptr() for t in (dists, pts, dirs, sdf, grad, color))
+            a.background_rgb = _lib.ptr(bgc)
+            a.n, a.m = batch, n_samples
+            a.inv_s, a.cos_anneal_ratio = inv_s, float(cos_anneal_ratio)
+            a.out_color, a.weights, a.cdf, a.inside_sphere = out_color.data_ptr(), weights.data_ptr(), cdf.data_ptr(), inside.data_ptr()
+            a.weight_sum, a.weight_max, a.gradient_error_acc = wsum.data_ptr(), wmax.data_ptr(), gacc.data_ptr()
+            _lib.check(lib.iron_neus_composite(C.byref(a), st))
+            gradient_error = gacc[0] / (gacc[1] + 1e-5)
+        return {
+            "color_fine": out_color,
+            "s_val": torch.full((batch, 1), 1.0 / inv_s, dtype=torch.float32, device=dev),
+            "cdf_fine": cdf,
+            "weight_sum": wsum,
+            "weight_max": wmax,
+            "gradients": grad.reshape(batch, n_samples, 3),
+            "weights": weights,
+            "gradient_error": gradient_error,
+            "inside_sphere": inside,
+        }

@@ -1,0 +1,131 @@
+"""SURVEY 8 row f-3 on the GPU: iron_amd.renderer.NeuSRenderer (HIP per-ray kernels of csrc/neus.hip + the batched network
+kernels) against the real reference's NeuSRenderer.render (golden G13) and against oracle/neus_ref.py on other
+configurations (no background model, constant background colour)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import cpu_sd, golden, golden_meta, rel_l2, state_hash, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _stage1():
+    from iron_amd.fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    torch.manual_seed(0)
+    nets = {
+        "sdf_network": SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                                  geometric_init=True, weight_norm=True),
+        "color_network": RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=8, skip_in=[4],
+                                          weight_norm=True, multires=10, multires_view=4, squeeze_out=True),
+        "nerf": NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True),
+        "deviation_network": SingleVarianceNetwork(0.3),
+    }
+    assert state_hash(nets) == golden_meta()["state_sha256_stage1"]
+    return nets
+
+
+def _renderer(nets, n_outside=32):
+    from iron_amd.renderer import NeuSRenderer
+    return NeuSRenderer(nets["nerf"].cuda(), nets["sdf_network"].cuda(), nets["deviation_network"].cuda(), nets["color_network"].cuda(),
+                        n_samples=64, n_importance=64, n_outside=n_outside, up_sample_steps=4, perturb=0.0)
+
+
+KEYS = ("color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error", "inside_sphere")
+
+
+def _report(out, ref, tag):
+    """max |d| per output; for the per-sample rows also the share of entries beyond 1e-4 (key + "_frac")."""
+    worst = {}
+    for k in KEYS:
+        a = out[k].detach().cpu().numpy()
+        assert tuple(a.shape) == tuple(np.asarray(ref[k]).shape), k
+        d = np.abs(a - np.asarray(ref[k]))
+        worst[k] = float(d.max())
+        if k in ("weights", "cdf_fine", "gradients"):
+            worst[k + "_frac"] = float((d > 1e-4).mean())
+    print(tag, " ".join("%s=%.1e" % kv for kv in worst.items()))
+    return worst
+
+
+def _check(w):
+    """Per-ray results are tight.  Per-sample rows are compared entry by entry although an up-sampled depth is an inverse
+    CDF through sections of weight ~1e-5, where an sdf difference of 1e-6 (split-fp16 core vs fp32) sharpened by
+    inv_s = 512 moves the depth a little: a handful of entries move by ~1e-3, the integrals do not."""
+    assert w["color_fine"] <= 1e-4 and w["weight_sum"] <= 1e-4 and w["weight_max"] <= 5e-4
+    assert w["gradient_error"] <= 1e-5 and w["s_val"] <= 1e-7
+    for k in ("weights", "cdf_fine", "gradients"):
+        assert w[k] <= 1e-2 and w[k + "_frac"] <= 0.01, (k, w[k], w[k + "_frac"])
+
+
+def test_neus_render_matches_reference_golden():
+    """The BASELINE C2 configuration (64 + 4 x 16 samples, NeRF background with 32 outside samples) on the 96 rays of G13."""
+    g = golden("g13_neus.npz")
+    r = _renderer(_stage1())
+    out = r.render(t(g["rays_o"]).cuda(), t(g["rays_d"]).cuda(), t(g["near"]).cuda(), t(g["far"]).cuda(), perturb_overwrite=0,
+                   background_rgb=None, cos_anneal_ratio=float(g["cos_anneal_ratio"]))
+    w = _report(out, g, "G13")
+    assert out["weights"].shape[1] == 64 + 64 + 32
+    _check(w)
+    assert rel_l2(out["color_fine"].cpu().numpy(), g["color_fine"]) <= 1e-4
+    assert np.array_equal(out["inside_sphere"].cpu().numpy(), g["inside_sphere"])
+
+
+@pytest.mark.parametrize("n_outside,bg", [(0, None), (0, (1.0, 1.0, 1.0)), (32, (0.2, 0.4, 0.6))])
+def test_neus_render_other_configurations_vs_oracle(n_outside, bg):
+    from oracle import iron_ref as R
+    from oracle import neus_ref as N
+    g = golden("g13_neus.npz")
+    nets = _stage1()
+    sc = N.NeusScene(cpu_sd(nets["sdf_network"]), R.SDFSpec(), cpu_sd(nets["color_network"]), cpu_sd(nets["nerf"]),
+                     nets["deviation_network"].variance.detach().clone(), n_outside=n_outside)
+    sel = slice(0, 96, 3)
+    args = [t(g[k])[sel] for k in ("rays_o", "rays_d", "near", "far")]
+    bgt = None if bg is None else torch.tensor([bg])
+    ref = N.render(sc, *args, background_rgb=bgt, cos_anneal_ratio=0.7)
+    r = _renderer(nets, n_outside)
+    out = r.render(*[a.cuda() for a in args], perturb_overwrite=0, background_rgb=None if bg is None else bgt.cuda(), cos_anneal_ratio=0.7)
+    w = _report(out, {k: ref[k].numpy() for k in KEYS}, "n_outside=%d bg=%s" % (n_outside, bg))
+    _check(w)
+    assert out["weights"].shape[1] == 128 + n_outside
+
+
+def test_up_sample_and_merge_kernels_vs_oracle():
+    """up_sample (+ sample_pdf) and the sorted merge on synthetic rows: ragged weights, flat CDF sections, ties."""
+    from oracle import neus_ref as N
+    r = _renderer(_stage1(), 0)
+    gen = torch.Generator().manual_seed(5)
+    n, m = 257, 80
+    o = torch.randn(n, 3, generator=gen) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    o = o - 2.5 * d
+    z = torch.sort(torch.rand(n, m, generator=gen) * 2.0 + 1.5, dim=-1)[0]
+    sdf = (o[:, None, :] + d[:, None, :] * z[..., None]).norm(dim=-1) - 0.6 + 0.02 * torch.randn(n, m, generator=gen)
+    for inv_s in (64.0, 512.0):
+        ref = N.up_sample(o, d, z, sdf, 16, inv_s)
+        got = r.up_sample(o.cuda(), d.cuda(), z.cuda(), sdf.cuda(), 16, inv_s).cpu()
+        # an inverse-CDF sample can land in the neighbouring section when u sits within rounding of a CDF knot
+        bad = (got - ref).abs() > 1e-5
+        print("up_sample inv_s=%g: max|d| %.2e, %d / %d beyond 1e-5" % (inv_s, float((got - ref).abs().max()), int(bad.sum()), bad.numel()))
+        assert float(bad.float().mean()) <= 2e-3
+        assert float((got - ref).abs().max()) <= 0.05
+        assert bool((got[:, 1:] >= got[:, :-1]).all())
+    new_z = torch.rand(n, 16, generator=gen) * 2.0 + 1.5
+    new_z[:, 3] = z[:, 10]  # ties: the old row's entry goes first (stable order of the concatenation)
+    new_z = torch.sort(new_z, dim=-1)[0]
+    new_s = torch.randn(n, 16, generator=gen)
+    zc, idx = torch.sort(torch.cat([z, new_z], dim=-1), dim=-1, stable=True)
+    sc = torch.gather(torch.cat([sdf, new_s], dim=-1), 1, idx)
+    gz, gs = r._merge(z.cuda(), sdf.cuda(), new_z.cuda(), new_s.cuda())
+    assert torch.equal(gz.cpu(), zc) and torch.equal(gs.cpu(), sc)
+
+
+def test_neus_refuses_cpu_tensors_and_perturb():
+    r = _renderer(_stage1())
+    g = golden("g13_neus.npz")
+    with pytest.raises(Exception):
+        r.render(t(g["rays_o"]), t(g["rays_d"]), t(g["near"]), t(g["far"]), perturb_overwrite=0)
+    with pytest.raises(NotImplementedError):
+        r.render(t(g["rays_o"]).cuda(), t(g["rays_d"]).cuda(), t(g["near"]).cuda(), t(g["far"]).cuda(), perturb_overwrite=1)
+    out = r.render(t(g["rays_o"])[:0].cuda(), t(g["rays_d"])[:0].cuda(), t(g["near"])[:0].cuda(), t(g["far"])[:0].cuda(), perturb_overwrite=0)
+    assert out["color_fine"].shape == (0, 3)
