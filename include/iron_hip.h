@@ -123,6 +123,9 @@ int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, const float* vi
  *                         (x/r, 1/r) parametrisation of render_core_outside (:163-172), pts [n*m,4]
  *   iron_neus_composite   render_core's alpha (logistic CDF), inside-sphere blend with the NeRF background, weights,
  *                         colour, weight_sum / weight_max, cdf, inside_sphere, eikonal statistics (:279-344, :174-178). */
+/* extract_fields' lattice (models/renderer.py:9-31): pts [nx*ny*nz,3] = meshgrid(xs, ys, zs) in 'ij' order; the field values
+ * are then one iron_sdf_forward (or any other batched query) over pts. */
+int iron_grid_points(const float* xs, const float* ys, const float* zs, int32_t nx, int32_t ny, int32_t nz, float* pts, void* stream);
 int iron_neus_linspace(const float* near, const float* far, const float* lin, int64_t n, int32_t m, float* z, void* stream);
 int iron_neus_outside_z(const float* far, const float* rev, int64_t n, int32_t m, float offset, float* z, void* stream);
 int iron_neus_points(const float* rays_o, const float* rays_d, const float* z, int64_t n, int32_t m, float* pts, void* stream);

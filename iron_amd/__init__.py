@@ -25,7 +25,7 @@ def install_as_models() -> None:
         pkg = types.ModuleType("models")
         pkg.__path__ = []  # mark as package
         sys.modules["models"] = pkg
-    for name in ("raytracer", "renderer_ggx", "rendering_func", "fields", "embedder"):
+    for name in ("raytracer", "renderer_ggx", "rendering_func", "fields", "embedder", "renderer", "network_conf"):
         mod = importlib.import_module("iron_amd." + name)
         sys.modules["models." + name] = mod
         setattr(pkg, name, mod)

@@ -97,6 +97,7 @@ SYMBOLS = {
     "iron_ggx_colocated": (C.c_int, [_F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "iron_composite_colocated": (C.c_int, [C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "iron_coloc_head": (C.c_int, [_I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "iron_grid_points": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "iron_neus_linspace": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
     "iron_neus_outside_z": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "iron_neus_points": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),

@@ -11,7 +11,7 @@ constexpr int kMaxSamples = 192;
 
 static inline int ray_grid(int64_t n) {
     const int64_t b = (n + 63) / 64;
-    return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+    return (int)(b < 16384 ? (b > 0 ? b : 1) : 16384);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -33,6 +33,16 @@ __global__ void k_neus_outside_z(const float* __restrict__ far, const float* __r
     const int64_t total = (int64_t)n * m;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
         z[i] = far[i / m] / rev[i % m] + offset;
+}
+
+// lattice points of extract_fields (renderer.py:9-31): pts[((i*ny)+j)*nz+k] = (xs[i], ys[j], zs[k])  ('ij' meshgrid order)
+__global__ void k_grid_points(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, int nx, int ny, int nz,
+                              float* __restrict__ pts) {
+    const int64_t total = (int64_t)nx * ny * nz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % nz), j = (int)((i / nz) % ny), a = (int)(i / ((int64_t)nz * ny));
+        pts[3 * i] = xs[a]; pts[3 * i + 1] = ys[j]; pts[3 * i + 2] = zs[k];
+    }
 }
 
 // pts[r][j] = o[r] + d[r] * z[r][j]
@@ -246,6 +256,15 @@ extern "C" int iron_neus_outside_z(const float* far, const float* rev, int64_t n
     if (n == 0) return IRON_OK;
     if (!far || !rev || !z) return IRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_neus_outside_z, dim3(ray_grid(n * m)), dim3(64), 0, (hipStream_t)stream, far, rev, (int)n, m, offset, z);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_grid_points(const float* xs, const float* ys, const float* zs, int32_t nx, int32_t ny, int32_t nz, float* pts, void* stream) {
+    if (nx < 0 || ny < 0 || nz < 0) return IRON_ERR_BAD_ARG;
+    if ((int64_t)nx * ny * nz == 0) return IRON_OK;
+    if (!xs || !ys || !zs || !pts) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_grid_points, dim3(ray_grid((int64_t)nx * ny * nz)), dim3(64), 0, (hipStream_t)stream, xs, ys, zs, nx, ny, nz, pts);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

@@ -11,9 +11,42 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
+
+
+def extract_fields(bound_min, bound_max, resolution, query_func, max_points: int = 1 << 22) -> np.ndarray:
+    """models/renderer.py:9-31: query_func on the resolution^3 lattice between the bounds -> float32 [res, res, res] (numpy).
+    The lattice is generated on the GPU in x-slabs of at most `max_points` points (the reference walks 64^3 blocks)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    axes = [torch.linspace(float(bound_min[i]), float(bound_max[i]), resolution).to(dev) for i in range(3)]
+    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    slab = max(1, min(resolution, max_points // (resolution * resolution)))
+    lib = _lib.load()
+    with torch.no_grad(), torch.cuda.device(dev):
+        for x0 in range(0, resolution, slab):
+            nx = min(slab, resolution - x0)
+            pts = torch.empty((nx * resolution * resolution, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.iron_grid_points(axes[0][x0:x0 + nx].data_ptr(), axes[1].data_ptr(), axes[2].data_ptr(), nx, resolution,
+                                            resolution, pts.data_ptr(), _lib.stream_ptr(dev)))
+            u[x0:x0 + nx] = query_func(pts).reshape(nx, resolution, resolution).detach().cpu().numpy()
+    return u
+
+
+def extract_geometry(bound_min, bound_max, resolution, threshold, query_func):
+    """models/renderer.py:34-42.  Marching cubes is the third-party `mcubes` there too; it is not part of this build."""
+    try:
+        import mcubes
+    except ImportError as e:  # same dependency as the reference
+        raise ImportError("extract_geometry needs PyMCubes (`mcubes`), as in models/renderer.py:36") from e
+    u = extract_fields(bound_min, bound_max, resolution, query_func)
+    vertices, triangles = mcubes.marching_cubes(u, threshold)
+    b_max_np = torch.as_tensor(bound_max).detach().cpu().numpy()
+    b_min_np = torch.as_tensor(bound_min).detach().cpu().numpy()
+    vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+    return vertices, triangles
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -85,6 +118,11 @@ class NeuSRenderer:
                 return z, sdf
             new_sdf = self.sdf_network.sdf(self._points(rays_o, rays_d, new_z_vals)).reshape(new_z_vals.shape)
             return self._merge(z_vals, _f32(sdf, "sdf"), new_z_vals, new_sdf)
+
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+        """renderer.py:455-462."""
+        return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
+                                query_func=lambda pts: -self.sdf_network.sdf(pts))
 
     # ---- render ---------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -1,6 +1,7 @@
 """Material query + the stage-2 render_fn, with the reference's surface:
     get_materials            <- models/rendering_func.py:5-16
     get_materials_comp       <- models/rendering_func.py:19-49
+    get_materials_multi      <- models/rendering_func.py:50-63
     make_render_fn(renderer) <- the driver's render_fn closure, render_surface.py:117-156
     make_render_fn_comp(renderer) <- render_fn_comp, render_surface.py:159-234
 
@@ -43,6 +44,15 @@ def get_materials_comp(network_dict, points, normals, features):
             "metallic_eta": run("metallic_eta_network", None),
             "metallic_k": run("metallic_k_network", None),
             "dielectric_eta": run("dielectric_eta_network", None)}
+
+
+def get_materials_multi(color_network_dict, points, normals, features, is_metal=False):
+    """models/rendering_func.py:50-63 (the `multi` network set: no channel-mean on the specular albedo, plus the 4-wide
+    points-only material vector)."""
+    return {"diffuse_albedo": color_network_dict["diffuse_albedo_network"](points, normals, -normals, features).abs(),
+            "specular_albedo": color_network_dict["specular_albedo_network"](points, normals, None, features).abs(),
+            "specular_roughness": color_network_dict["specular_roughness_network"](points, normals, None, features).abs() + 0.01,
+            "material_vector": color_network_dict["material_network"](points, None, None, features).abs()}
 
 
 class CompRenderFn:

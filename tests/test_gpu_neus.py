@@ -129,3 +129,21 @@ def test_neus_refuses_cpu_tensors_and_perturb():
         r.render(t(g["rays_o"]).cuda(), t(g["rays_d"]).cuda(), t(g["near"]).cuda(), t(g["far"]).cuda(), perturb_overwrite=1)
     out = r.render(t(g["rays_o"])[:0].cuda(), t(g["rays_d"])[:0].cuda(), t(g["near"])[:0].cuda(), t(g["far"])[:0].cuda(), perturb_overwrite=0)
     assert out["color_fine"].shape == (0, 3)
+
+
+def test_extract_fields_lattice():
+    """extract_fields (renderer.py:9-31): lattice order and values vs the oracle SDF on an explicit meshgrid."""
+    from oracle import iron_ref as R
+    from iron_amd.renderer import extract_fields
+    nets = _stage1()
+    sdf = nets["sdf_network"].cuda()
+    lo, hi, res = torch.tensor([-0.9, -0.7, -0.8]), torch.tensor([0.8, 0.9, 0.7]), 37
+    u = extract_fields(lo, hi, res, lambda p: -sdf.sdf(p), max_points=5000)   # several ragged slabs
+    assert u.shape == (res, res, res) and u.dtype == np.float32
+    axes = [torch.linspace(float(lo[i]), float(hi[i]), res) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(*axes, indexing="ij")
+    pts = torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3)
+    ref = -R.sdf_forward(cpu_sd(nets["sdf_network"]), R.SDFSpec(), pts)[:, 0].reshape(res, res, res).numpy()
+    assert np.abs(u - ref).max() <= 2e-5
+    u2 = extract_fields(lo, hi, res, lambda p: -sdf.sdf(p))
+    assert np.array_equal(u, u2)
