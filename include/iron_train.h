@@ -1,0 +1,97 @@
+/* iron_train.h -- C ABI of iron_amd/csrc/libiron_train.so: the BACKWARD passes of the stage-2 render operators
+ * (BASELINE config C3).  gfx950 only.
+ *
+ * The reference trains through torch.autograd: `SDFNetwork.get_all(is_training=True)` builds a second-order graph
+ * (models/fields.py:120-137), `RenderingNetwork.forward` and `GGXColocatedRenderer.forward` are ordinary differentiable
+ * torch code (models/fields.py:203-239, models/renderer_ggx.py:82-146), and `loss.backward()` in render_surface.py:533-653
+ * walks that graph.  Each entry below is the backward of ONE of those operators, evaluated in closed form on the GPU; the
+ * Python side (iron_amd/autograd.py) wraps forward (libiron_hip.so) + backward (this library) as torch.autograd.Function
+ * so the reference's own render_fn / reparam_points / loss code runs unchanged on top.
+ *
+ * Method: the hit points of one call are processed as a batch, layer by layer, in fp32.  The forward activations are
+ * recomputed from the inputs and kept in the caller's workspace (HBM is 288 GB: 37 KB per point for the SDF net), the
+ * per-layer products (Z = X W^T, dX = dZ W, dW = dZ^T X with K = number of points) are plain SGEMMs issued to rocBLAS,
+ * everything between them (positional encoding and its derivative, softplus-100 first and second derivative, the
+ * forward-mode tangent rows that carry d(normal)/d(theta), weight-norm fold and its backward, column sums, the GGX
+ * derivative) is hand-written HIP.
+ *
+ * Conventions as iron_hip.h: device pointers, fp32 row-major contiguous, caller-owned buffers and workspace, work enqueued
+ * on `stream`, IRON_OK or a negative iron_status.  Parameter gradients are WRITTEN (not accumulated) to the d_* pointers
+ * of each layer.
+ */
+#ifndef IRON_TRAIN_H
+#define IRON_TRAIN_H
+
+#include "iron_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One linear layer as the reference stores it (nn.utils.weight_norm: W = weight_g * weight_v / ||weight_v||_row). */
+typedef struct iron_train_layer {
+    const float* weight_v; /* [out,in]                                        */
+    const float* weight_g; /* [out] or NULL (plain nn.Linear: W = weight_v)   */
+    const float* bias;     /* [out]                                           */
+    float* d_weight_v;     /* [out,in] out                                    */
+    float* d_weight_g;     /* [out] out (ignored when weight_g is NULL)       */
+    float* d_bias;         /* [out] out                                       */
+    int32_t out_dim, in_dim;
+} iron_train_layer;
+
+/* SDFNetwork (models/fields.py:9-98): PE(multires) -> n_linear layers, softplus(beta=100) between them, one skip layer
+ * whose input is cat[x, PE]/sqrt(2); scale must be 1. */
+typedef struct iron_sdf_train_desc {
+    int32_t n_linear;   /* 9 for the 8x256 network */
+    int32_t multires;   /* 6 */
+    int32_t skip_layer; /* 4, or -1 */
+    const iron_train_layer* layers;
+} iron_sdf_train_desc;
+
+/* Backward of get_all (fields.py:120-137): given dL/d sdf [n], dL/d feature [n, d_out-1], dL/d gradient [n,3] (each may
+ * be NULL = zero) at the points x [n,3], writes dL/d(weight_v, weight_g, bias) of every layer.  The second-order part
+ * (dL/d gradient) is the reverse pass over a forward-mode tangent along v = dL/d gradient: <v, grad_x sdf> is the
+ * directional derivative of the network along v, so its parameter gradient is one more (value, tangent) reverse sweep. */
+size_t iron_sdf_backward_workspace_bytes(const iron_sdf_train_desc* desc, int64_t n);
+int iron_sdf_backward(const iron_sdf_train_desc* desc, const float* x, int64_t n, const float* d_sdf, const float* d_feature,
+                      const float* d_gradient, void* workspace, size_t workspace_bytes, void* stream);
+
+/* RenderingNetwork (models/fields.py:141-239): input cat per `mode` (IRON_MODE_*), ReLU MLP with an optional skip layer,
+ * y = output_scale * (z + output_bias), optional squeeze_out_scale * sigmoid(y). */
+typedef struct iron_render_train_desc {
+    int32_t n_linear;
+    int32_t mode;
+    int32_t multires, multires_view;
+    int32_t d_feature, d_out;
+    int32_t skip_layer; /* -1: none */
+    int32_t squeeze_out;
+    float output_bias, output_scale, squeeze_out_scale;
+    const iron_train_layer* layers;
+} iron_render_train_desc;
+
+/* Backward of RenderingNetwork.forward: d_out [n,d_out] -> parameter gradients and (each nullable) d_points [n,3],
+ * d_normals [n,3], d_view_dirs [n,3], d_features [n,d_feature].  normals / view_dirs may be NULL where the mode ignores
+ * them. */
+size_t iron_render_backward_workspace_bytes(const iron_render_train_desc* desc, int64_t n);
+int iron_render_backward(const iron_render_train_desc* desc, const float* points, const float* normals, const float* view_dirs,
+                         const float* features, int64_t n, const float* d_out, float* d_points, float* d_normals, float* d_view_dirs,
+                         float* d_features, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of GGXColocatedRenderer.forward (models/renderer_ggx.py:82-146).  Upstream d_diffuse_rgb / d_specular_rgb /
+ * d_rgb [n,3] (each nullable); outputs (each nullable): d_light [1] (device, written), d_distance [n], d_normal [n,3],
+ * d_viewdir [n,3], d_diffuse_albedo [n,3], d_specular_albedo [n,3], d_roughness [n].  The two Mitsuba tables are
+ * piecewise constant in (cos, alpha), so they carry no gradient (torch gives none either: integer indexing). */
+int iron_ggx_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
+                                const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                                const float* tab_trans, const float* tab_diff, int64_t n, const float* d_diffuse_rgb,
+                                const float* d_specular_rgb, const float* d_rgb, float* d_light, float* d_distance, float* d_normal,
+                                float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo, float* d_roughness, void* stream);
+
+/* Diagnostics: last hipError_t / rocblas_status seen by this library on the calling thread. */
+int iron_train_last_hip_error(void);
+int iron_train_last_blas_status(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -124,8 +124,65 @@ SYMBOLS = {
                                  C.POINTER(iron_shade_out), _P, _SZ, _P]),
 }
 
+# ---- libiron_train.so (include/iron_train.h): backward passes, loaded on first use (it pulls rocBLAS in) ----
+class iron_train_layer(C.Structure):
+    _fields_ = [("weight_v", C.c_void_p), ("weight_g", C.c_void_p), ("bias", C.c_void_p), ("d_weight_v", C.c_void_p),
+                ("d_weight_g", C.c_void_p), ("d_bias", C.c_void_p), ("out_dim", C.c_int32), ("in_dim", C.c_int32)]
+
+
+class iron_sdf_train_desc(C.Structure):
+    _fields_ = [("n_linear", C.c_int32), ("multires", C.c_int32), ("skip_layer", C.c_int32), ("layers", C.POINTER(iron_train_layer))]
+
+
+class iron_render_train_desc(C.Structure):
+    _fields_ = [("n_linear", C.c_int32), ("mode", C.c_int32), ("multires", C.c_int32), ("multires_view", C.c_int32),
+                ("d_feature", C.c_int32), ("d_out", C.c_int32), ("skip_layer", C.c_int32), ("squeeze_out", C.c_int32),
+                ("output_bias", C.c_float), ("output_scale", C.c_float), ("squeeze_out_scale", C.c_float),
+                ("layers", C.POINTER(iron_train_layer))]
+
+
+TRAIN_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libiron_train.so")
+TRAIN_SYMBOLS = {
+    "iron_sdf_backward_workspace_bytes": (_SZ, [C.POINTER(iron_sdf_train_desc), _I64]),
+    "iron_sdf_backward": (C.c_int, [C.POINTER(iron_sdf_train_desc), _P, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "iron_render_backward_workspace_bytes": (_SZ, [C.POINTER(iron_render_train_desc), _I64]),
+    "iron_render_backward": (C.c_int, [C.POINTER(iron_render_train_desc), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "iron_ggx_colocated_backward": (C.c_int, [_F] + [_P] * 8 + [_I64] + [_P] * 10 + [_P]),
+    "iron_train_last_hip_error": (C.c_int, []),
+    "iron_train_last_blas_status": (C.c_int, []),
+}
+
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
+_train_lib: Optional[C.CDLL] = None
+
+
+def load_train() -> C.CDLL:
+    """dlopen libiron_train.so (the backward passes) and bind every symbol of include/iron_train.h."""
+    global _train_lib
+    with _lock:
+        if _train_lib is not None:
+            return _train_lib
+        path = os.environ.get("IRON_TRAIN_LIB") or TRAIN_LIB_PATH
+        if not os.path.exists(path):
+            raise IronError("libiron_train.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no autograd fallback for the HIP operators)" % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in TRAIN_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _train_lib = lib
+        return lib
+
+
+def check_train(status: int) -> None:
+    if status != IRON_OK:
+        lib = load_train()
+        msg = load().iron_strerror(status).decode()
+        if status == -3:
+            msg += " [hipError_t=%d rocblas_status=%d]" % (lib.iron_train_last_hip_error(), lib.iron_train_last_blas_status())
+        raise IronError("libiron_train: %s" % msg)
 
 
 def load() -> C.CDLL:

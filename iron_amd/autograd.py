@@ -1,0 +1,229 @@
+"""torch.autograd.Function wrappers that make the HIP operators trainable (BASELINE config C3).
+
+The reference trains by running its ordinary torch modules under autograd (render_surface.py:533-653).  Here each
+operator's forward is the inference HIP kernel (libiron_hip.so) and its backward is the closed-form HIP / rocBLAS pass of
+libiron_train.so (include/iron_train.h):
+
+    SDFGetAllFn      SDFNetwork.get_all(is_training=True) / .gradient       models/fields.py:106-137 (second order)
+    RenderNetFn      RenderingNetwork.forward                               models/fields.py:203-239
+    GGXColocatedFn   GGXColocatedRenderer.forward                           models/renderer_ggx.py:82-146
+
+so `render_camera(..., is_training=True)`, the reference's `reparam_points`, its `render_fn` closure and its loss code
+run unchanged on top and `loss.backward()` fills `.grad` of weight_g / weight_v / bias / light exactly as there.  There is
+no fallback: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+def _layer_params(net) -> List[torch.Tensor]:
+    """Flat parameter list in the order the Functions take / return them: per layer (weight_g, weight_v, bias) or
+    (weight, bias)."""
+    out = []
+    for lin in net._layers():
+        if getattr(lin, "has_weight_norm", False):
+            out += [lin.weight_g, lin.weight_v, lin.bias]
+        else:
+            out += [lin.weight, lin.bias]
+    return out
+
+
+def _train_layers(net, device):
+    """iron_train_layer array over the module's current parameters + freshly allocated gradient buffers (returned in
+    _layer_params order)."""
+    layers = net._layers()
+    arr = (_lib.iron_train_layer * len(layers))()
+    keep, grads = [], []
+    for i, lin in enumerate(layers):
+        wn = getattr(lin, "has_weight_norm", False)
+        v = (lin.weight_v if wn else lin.weight).detach()
+        b = lin.bias.detach()
+        v = _lib.require_cuda_f32(v, "weight")
+        b = _lib.require_cuda_f32(b, "bias")
+        dv, db = torch.empty_like(v), torch.empty_like(b)
+        arr[i].weight_v, arr[i].bias, arr[i].d_weight_v, arr[i].d_bias = v.data_ptr(), b.data_ptr(), dv.data_ptr(), db.data_ptr()
+        arr[i].out_dim, arr[i].in_dim = v.shape[0], v.shape[1]
+        keep += [v, b]
+        if wn:
+            g = _lib.require_cuda_f32(lin.weight_g.detach(), "weight_g")
+            dg = torch.empty_like(g)
+            arr[i].weight_g, arr[i].d_weight_g = g.data_ptr(), dg.data_ptr()
+            keep.append(g)
+            grads += [dg, dv, db]
+        else:
+            arr[i].weight_g, arr[i].d_weight_g = None, None
+            grads += [dv, db]
+    return arr, keep, grads
+
+
+def _opt(t: Optional[torch.Tensor], shape=None) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = _lib.require_cuda_f32(t, "upstream gradient")
+    return t.reshape(shape) if shape is not None else t
+
+
+class SDFGetAllFn(torch.autograd.Function):
+    """(sdf [n,1], feature [n,d_out-1], gradient [n,3]) = get_all(x); differentiable w.r.t. the network parameters, to
+    second order through `gradient` (the tangent sweep of iron_sdf_backward).  x itself gets no gradient: the reference
+    evaluates get_all on the tracer's detached hit points (raytracer.py:622) and on sampled eikonal points."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        ctx.set_materialize_grads(False)
+        ctx.net = net
+        with torch.no_grad():
+            sdf, feat, grad = net.get_all(x, is_training=False)
+        ctx.save_for_backward(x.detach())
+        return sdf, feat, grad
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_feat, d_grad):
+        net = ctx.net
+        (x,) = ctx.saved_tensors
+        x = _lib.require_cuda_f32(x, "x").reshape(-1, 3)
+        n = x.shape[0]
+        dev = x.device
+        if net.scale != 1 or len(net.skip_in) > 1:
+            raise _lib.IronError("SDF backward supports scale = 1 and at most one skip layer")
+        lib = _lib.load_train()
+        with torch.cuda.device(dev):
+            arr, keep, grads = _train_layers(net, dev)
+            desc = _lib.iron_sdf_train_desc()
+            desc.n_linear, desc.multires = net.num_layers - 1, net.multires
+            desc.skip_layer = net.skip_in[0] if net.skip_in else -1
+            desc.layers = arr
+            d_sdf, d_feat, d_grad = _opt(d_sdf, (-1,)), _opt(d_feat, (n, -1)), _opt(d_grad, (-1, 3))
+            nbytes = lib.iron_sdf_backward_workspace_bytes(C.byref(desc), n)
+            if nbytes == 0:
+                raise _lib.IronError("unsupported SDFNetwork shape for the backward pass")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check_train(lib.iron_sdf_backward(C.byref(desc), x.data_ptr(), n, _lib.ptr(d_sdf), _lib.ptr(d_feat), _lib.ptr(d_grad),
+                                                   ws.data_ptr(), nbytes, _lib.stream_ptr(dev)))
+        del keep
+        return (None, None) + tuple(grads)
+
+
+class RenderNetFn(torch.autograd.Function):
+    """out = RenderingNetwork(points, normals, view_dirs, features); differentiable w.r.t. all four inputs and the
+    parameters."""
+
+    @staticmethod
+    def forward(ctx, net, points, normals, view_dirs, feats, *params):
+        ctx.net = net
+        with torch.no_grad():
+            out = net._forward_values(points, normals, view_dirs, feats)
+        ctx.has = (normals is not None, view_dirs is not None)
+        ctx.shapes = (points.shape, None if normals is None else normals.shape, None if view_dirs is None else view_dirs.shape, feats.shape)
+        ctx.save_for_backward(points.detach(), feats.detach(), *([normals.detach()] if normals is not None else []),
+                              *([view_dirs.detach()] if view_dirs is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net = ctx.net
+        saved = list(ctx.saved_tensors)
+        pts, feats = saved[0], saved[1]
+        k = 2
+        nrm = vd = None
+        if ctx.has[0]:
+            nrm = saved[k]; k += 1
+        if ctx.has[1]:
+            vd = saved[k]
+        pts = _lib.require_cuda_f32(pts, "points").reshape(-1, 3)
+        n = pts.shape[0]
+        dev = pts.device
+        feats = _lib.require_cuda_f32(feats, "features").reshape(n, -1)
+        nrm = _lib.require_cuda_f32(nrm, "normals").reshape(-1, 3) if nrm is not None else None
+        vd = _lib.require_cuda_f32(vd, "view_dirs").reshape(-1, 3) if vd is not None else None
+        lib = _lib.load_train()
+        with torch.cuda.device(dev):
+            arr, keep, grads = _train_layers(net, dev)
+            desc = _lib.iron_render_train_desc()
+            desc.n_linear, desc.mode = net.num_layers - 1, _lib.MODES[net.mode]
+            desc.multires, desc.multires_view = net.multires, net.multires_view
+            desc.d_feature, desc.d_out = net.d_feature, net.d_out
+            if len(net.skip_in) > 1:
+                raise _lib.IronError("RenderingNetwork backward supports at most one skip layer")
+            desc.skip_layer = net.skip_in[0] if net.skip_in else -1
+            desc.squeeze_out = 1 if net.squeeze_out else 0
+            desc.output_bias, desc.output_scale, desc.squeeze_out_scale = float(net.output_bias), float(net.output_scale), float(net.squeeze_out_scale)
+            desc.layers = arr
+            g = _lib.require_cuda_f32(d_out, "d_out").reshape(n, net.d_out)
+            need = ctx.needs_input_grad  # (net, points, normals, view_dirs, feats, *params)
+            d_pts = torch.empty_like(pts) if need[1] else None
+            d_nrm = torch.empty_like(nrm) if (nrm is not None and need[2]) else None
+            d_vd = torch.empty_like(vd) if (vd is not None and need[3]) else None
+            d_ft = torch.empty_like(feats) if need[4] else None
+            nbytes = lib.iron_render_backward_workspace_bytes(C.byref(desc), n)
+            if nbytes == 0:
+                raise _lib.IronError("unsupported RenderingNetwork shape for the backward pass")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check_train(lib.iron_render_backward(C.byref(desc), pts.data_ptr(), _lib.ptr(nrm), _lib.ptr(vd), feats.data_ptr(), n, g.data_ptr(),
+                                                      _lib.ptr(d_pts), _lib.ptr(d_nrm), _lib.ptr(d_vd), _lib.ptr(d_ft), ws.data_ptr(), nbytes,
+                                                      _lib.stream_ptr(dev)))
+        del keep
+        sp, sn, sv, sf = ctx.shapes
+        return (None,
+                d_pts.reshape(sp) if d_pts is not None else None,
+                d_nrm.reshape(sn) if d_nrm is not None else None,
+                d_vd.reshape(sv) if d_vd is not None else None,
+                d_ft.reshape(sf) if d_ft is not None else None) + tuple(grads)
+
+
+class GGXColocatedFn(torch.autograd.Function):
+    """(diffuse_rgb, specular_rgb, rgb) = GGXColocatedRenderer(light, distance, normal, viewdir, kd, ks, roughness)."""
+
+    @staticmethod
+    def forward(ctx, renderer, light, distance, normal, viewdir, kd, ks, rough):
+        ctx.set_materialize_grads(False)
+        ctx.renderer = renderer
+        light_t = light if torch.is_tensor(light) else None
+        ctx.light_shape = None if light_t is None else light_t.shape
+        ctx.light_value = float(light)
+        with torch.no_grad():
+            out = renderer._forward_values(ctx.light_value, distance, normal, viewdir, kd, ks, rough)
+        ctx.shapes = (distance.shape, normal.shape, viewdir.shape, kd.shape, ks.shape, rough.shape)
+        ctx.save_for_backward(distance.detach(), normal.detach(), viewdir.detach(), kd.detach(), ks.detach(), rough.detach())
+        return out["diffuse_rgb"], out["specular_rgb"], out["rgb"]
+
+    @staticmethod
+    def backward(ctx, g_diff, g_spec, g_rgb):
+        dist, nrm, vd, kd, ks, rough = ctx.saved_tensors
+        nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
+        n = nrm.shape[0]
+        dev = nrm.device
+        sh = list(ctx.shapes[1][:-1])
+        dist = _lib.require_cuda_f32(dist, "distance").reshape(-1)
+        vd = _lib.require_cuda_f32(vd, "viewdir").reshape(-1, 3)
+        kd = _lib.require_cuda_f32(kd, "diffuse_albedo").reshape(-1, 3)
+        ks = _lib.require_cuda_f32(ks.expand(sh + [3]), "specular_albedo").reshape(-1, 3)
+        rough = _lib.require_cuda_f32(rough, "specular_roughness").reshape(-1)
+        t1, t2 = ctx.renderer._tables_on(dev)
+        g_diff, g_spec, g_rgb = _opt(g_diff, (-1, 3)), _opt(g_spec, (-1, 3)), _opt(g_rgb, (-1, 3))
+        lib = _lib.load_train()
+        with torch.cuda.device(dev):
+            d_light = torch.zeros(1, dtype=torch.float32, device=dev)
+            d_dist, d_rough = torch.empty_like(dist), torch.empty_like(rough)
+            d_nrm, d_vd, d_kd, d_ks = (torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(4))
+            _lib.check_train(lib.iron_ggx_colocated_backward(ctx.light_value, dist.data_ptr(), nrm.data_ptr(), vd.data_ptr(), kd.data_ptr(),
+                                                             ks.data_ptr(), rough.data_ptr(), t1.data_ptr(), t2.data_ptr(), n, _lib.ptr(g_diff),
+                                                             _lib.ptr(g_spec), _lib.ptr(g_rgb), d_light.data_ptr(), d_dist.data_ptr(),
+                                                             d_nrm.data_ptr(), d_vd.data_ptr(), d_kd.data_ptr(), d_ks.data_ptr(),
+                                                             d_rough.data_ptr(), _lib.stream_ptr(dev)))
+        s_dist, s_nrm, s_vd, s_kd, s_ks, s_rough = ctx.shapes
+        d_ks = d_ks.reshape(sh + [3])
+        if s_ks[-1] == 1:  # a [...,1] albedo was broadcast over the channels
+            d_ks = d_ks.sum(dim=-1, keepdim=True)
+        return (None, d_light.reshape(ctx.light_shape) if ctx.light_shape is not None else None, d_dist.reshape(s_dist), d_nrm.reshape(s_nrm),
+                d_vd.reshape(s_vd), d_kd.reshape(s_kd), d_ks.reshape(s_ks), d_rough.reshape(s_rough))
+
+
+def any_requires_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)

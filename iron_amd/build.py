@@ -14,10 +14,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libiron_hip.so")
+LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/iron_train.h); links rocBLAS
 OBJ_DIR = os.path.join(CSRC, "build")
 
 SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "neus.hip", "profile.hip"]
-HEADERS = ["iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
+TRAIN_SOURCES = ["train.hip"]
+HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
 
 BASE_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -44,7 +46,7 @@ def _hipcc() -> str:
 
 def _digest(extra_flags) -> str:
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
+    for name in SOURCES + TRAIN_SOURCES + HEADERS:
         p = os.path.join(CSRC, name)
         if os.path.exists(p):
             with open(p, "rb") as f:
@@ -59,7 +61,7 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "stamp")
     dig = _digest(extra_flags)
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_TRAIN) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -87,6 +89,13 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # the training library: one source, no MFMA cores (its GEMMs are rocBLAS SGEMMs)
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
+    cmd = ([hipcc] + BASE_FLAGS + extra_flags + ["-shared", "-o", LIB_TRAIN] + [os.path.join(CSRC, s) for s in TRAIN_SOURCES]
+           + ["-L" + rocm_lib, "-L/opt/rocm/lib", "-lrocblas"])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for the training library:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as f:
         f.write(dig)
     if verbose:

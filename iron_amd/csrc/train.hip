@@ -1,0 +1,644 @@
+// Backward passes of the stage-2 render operators: see include/iron_train.h.
+// Layer-wise batched formulation: activations recomputed in fp32 and kept in the caller's workspace, per-layer products on
+// rocBLAS SGEMM (plain GEMMs with K = number of points), all glue hand-written below.  One translation unit, its own
+// shared library (libiron_train.so) so the inference library does not pull rocBLAS in.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <mutex>
+
+#include "../../include/iron_train.h"
+
+namespace iron_train {
+
+thread_local int g_hip_error = 0;
+thread_local int g_blas_status = 0;
+
+#define TR_HIP(expr)                                 \
+    do {                                             \
+        hipError_t _e = (expr);                      \
+        if (_e != hipSuccess) {                      \
+            g_hip_error = (int)_e;                   \
+            return IRON_ERR_HIP;                     \
+        }                                            \
+    } while (0)
+#define TR_BLAS(expr)                                \
+    do {                                             \
+        rocblas_status _s = (expr);                  \
+        if (_s != rocblas_status_success) {          \
+            g_blas_status = (int)_s;                 \
+            return IRON_ERR_HIP;                     \
+        }                                            \
+    } while (0)
+#define TR_TRY(expr)                \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != IRON_OK) return _r; \
+    } while (0)
+
+static rocblas_handle blas_for_current_device() {
+    static std::mutex mu;
+    static rocblas_handle handles[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!handles[dev]) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
+        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+        handles[dev] = h;
+    }
+    return handles[dev];
+}
+
+// row-major C[m,n] = op(A) op(B) + beta C;  A is [m,k] (or [k,m] when ta), B is [k,n] (or [n,k] when tb)
+static int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float beta,
+                   float* C, int ldc) {
+    if (m == 0 || n == 0) return IRON_OK;
+    const float one = 1.0f;
+    TR_BLAS(rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none,
+                          n, m, k, &one, B, ldb, A, lda, &beta, C, ldc));
+    return IRON_OK;
+}
+
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    float* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += count * sizeof(float);
+        return p;
+    }
+};
+
+static inline dim3 grid1(int64_t total, int block = 256) {
+    int64_t b = (total + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > 65536) b = 65536;
+    return dim3((unsigned)b);
+}
+#define GRID_STRIDE(i, total) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- positional encoding (models/embedder.py:6-54): [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] ------------
+__device__ __forceinline__ int pe_width(int L) { return 3 + 6 * L; }
+// value of PE column c at x[3]; *dv = derivative of that column w.r.t. its coordinate x[comp]; *comp = which coordinate
+__device__ __forceinline__ float pe_col(const float* x, int c, float* dv, int* comp) {
+    if (c < 3) { *dv = 1.0f; *comp = c; return x[c]; }
+    const int k = (c - 3) / 6, r = (c - 3) % 6;
+    const float f = (float)(1 << k);
+    *comp = r % 3;
+    const float a = x[*comp] * f;
+    float s, co;
+    sincosf(a, &s, &co);
+    if (r < 3) { *dv = f * co; return s; }
+    *dv = -f * s;
+    return co;
+}
+
+// ---- weight norm (torch._weight_norm, dim 0) ------------------------------------------------------------------------------------
+__global__ void k_wn_fold(const float* __restrict__ v, const float* __restrict__ g, int out, int in, float* __restrict__ W) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    float nrm = 1.0f, gr = 1.0f;
+    if (g) {
+        float s = 0.0f;
+        for (int c = lane; c < in; c += 64) { const float t = v[(size_t)r * in + c]; s += t * t; }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        nrm = sqrtf(s);
+        gr = g[r];
+    }
+    for (int c = lane; c < in; c += 64) W[(size_t)r * in + c] = g ? v[(size_t)r * in + c] * (gr / nrm) : v[(size_t)r * in + c];
+}
+
+__global__ void k_wn_back(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ dW, int out, int in,
+                          float* __restrict__ dv, float* __restrict__ dg) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!g) {
+        for (int c = lane; c < in; c += 64) dv[(size_t)r * in + c] = dW[(size_t)r * in + c];
+        return;
+    }
+    float s = 0.0f, d = 0.0f;
+    for (int c = lane; c < in; c += 64) {
+        const float t = v[(size_t)r * in + c];
+        s += t * t;
+        d += dW[(size_t)r * in + c] * t;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); d += __shfl_xor(d, o, 64); }
+    const float nrm = sqrtf(s), gr = g[r];
+    if (lane == 0 && dg) dg[r] = d / nrm;
+    const float k1 = gr / nrm, k2 = d / s;
+    for (int c = lane; c < in; c += 64) dv[(size_t)r * in + c] = k1 * (dW[(size_t)r * in + c] - v[(size_t)r * in + c] * k2);
+}
+
+// out[c] += sum over `rows` rows of Z[:, c]   (out pre-zeroed; blocks of 256 rows, one atomic per column per block)
+__global__ void k_colsum(const float* __restrict__ Z, int rows, int cols, int ld, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
+    float s = 0.0f;
+    for (int r = r0; r < r1; ++r) s += Z[(size_t)r * ld + c];
+    atomicAdd(&out[c], s);
+}
+
+// ---- SDF network ----------------------------------------------------------------------------------------------------------------
+// rows [0,m): value; rows [m,2m): tangent along v (only when v != NULL)
+__global__ void k_sdf_in(const float* __restrict__ x, const float* __restrict__ v, int m, int L, float* __restrict__ in0) {
+    const int D = pe_width(L);
+    GRID_STRIDE(i, (int64_t)m * D) {
+        const int p = (int)(i / D), c = (int)(i % D);
+        float dv; int comp;
+        const float val = pe_col(x + 3 * (size_t)p, c, &dv, &comp);
+        in0[i] = val;
+        if (v) in0[(size_t)m * D + i] = dv * v[3 * (size_t)p + comp];
+    }
+}
+
+__device__ __forceinline__ void softplus100(float z, float* a, float* s1, float* s2) {
+    const float bz = 100.0f * z;
+    if (bz > 20.0f) { *a = z; *s1 = 1.0f; *s2 = 0.0f; return; }  // F.softplus threshold
+    const float e = expf(bz);
+    *a = log1pf(e) / 100.0f;
+    *s1 = e / (e + 1.0f);
+    *s2 = 100.0f * (*s1) * (1.0f - *s1);
+}
+
+// Z [R, out] (R = m or 2m): add bias to the value rows in place; next[:, 0:out) = (softplus(z), sigma'(z) zdot) * sc
+__global__ void k_sdf_act(float* __restrict__ Z, const float* __restrict__ bias, int m, int out, int tangent, float sc, float* __restrict__ next,
+                          int ld_next) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int p = (int)(i / out), c = (int)(i % out);
+        const float z = Z[i] + bias[c];
+        Z[i] = z;
+        float a, s1, s2;
+        softplus100(z, &a, &s1, &s2);
+        next[(size_t)p * ld_next + c] = a * sc;
+        if (tangent) next[(size_t)(m + p) * ld_next + c] = s1 * Z[(size_t)m * out + i] * sc;
+    }
+}
+
+// dst[:, col0:col0+w) = src[:, 0:w) * sc   over `rows` rows
+__global__ void k_copy_cols(const float* __restrict__ src, int ld_src, int rows, int w, float sc, float* __restrict__ dst, int ld_dst, int col0) {
+    GRID_STRIDE(i, (int64_t)rows * w) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        dst[(size_t)r * ld_dst + col0 + c] = src[(size_t)r * ld_src + c] * sc;
+    }
+}
+
+// dst[:, 0:w) += src[:, col0:col0+w) * sc
+__global__ void k_add_cols(const float* __restrict__ src, int ld_src, int col0, int rows, int w, float sc, float* __restrict__ dst, int ld_dst) {
+    GRID_STRIDE(i, (int64_t)rows * w) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        dst[(size_t)r * ld_dst + c] += src[(size_t)r * ld_src + col0 + c] * sc;
+    }
+}
+
+__global__ void k_sdf_seed(const float* __restrict__ d_sdf, const float* __restrict__ d_feat, int m, int out, int tangent, float* __restrict__ dZ) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int p = (int)(i / out), c = (int)(i % out);
+        dZ[i] = c == 0 ? (d_sdf ? d_sdf[p] : 0.0f) : (d_feat ? d_feat[(size_t)p * (out - 1) + c - 1] : 0.0f);
+        if (tangent) dZ[(size_t)m * out + i] = c == 0 ? 1.0f : 0.0f;  // d<v, grad sdf>/d(tangent output 0) = 1
+    }
+}
+
+// reverse of k_sdf_act: dX [R, ld_dx] holds dL/d(next input) for the columns [0,out); writes dZ [R, out]
+__global__ void k_sdf_act_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, int tangent, float sc,
+                               float* __restrict__ dZ) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int p = (int)(i / out), c = (int)(i % out);
+        float a, s1, s2;
+        softplus100(Z[i], &a, &s1, &s2);
+        const float abar = dX[(size_t)p * ld_dx + c] * sc;
+        if (tangent) {
+            const float adotbar = dX[(size_t)(m + p) * ld_dx + c] * sc;
+            dZ[i] = s1 * abar + s2 * Z[(size_t)m * out + i] * adotbar;
+            dZ[(size_t)m * out + i] = s1 * adotbar;
+        } else {
+            dZ[i] = s1 * abar;
+        }
+    }
+}
+
+constexpr int kSdfChunk = 65536;
+constexpr int kMaxLayers = 16;
+
+struct SdfPlan {
+    int L, m_max;
+    float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *IN[kMaxLayers], *Z[kMaxLayers];
+    float *dZ, *dX;
+    size_t bytes;
+};
+
+static int sdf_plan(const iron_sdf_train_desc* d, int64_t n, void* ws, SdfPlan& P) {
+    if (!d || !d->layers || d->n_linear < 2 || d->n_linear > kMaxLayers || d->multires < 0 || d->multires > 12) return IRON_ERR_BAD_ARG;
+    const int L = d->n_linear;
+    const int D0 = 3 + 6 * d->multires;
+    if (d->layers[0].in_dim != D0) return IRON_ERR_UNSUPPORTED;
+    for (int l = 1; l < L; ++l) {
+        const int expect = d->layers[l - 1].out_dim + (l == d->skip_layer ? D0 : 0);
+        if (d->layers[l].in_dim != expect) return IRON_ERR_UNSUPPORTED;
+    }
+    P.L = L;
+    P.m_max = (int)(n < kSdfChunk ? (n > 0 ? n : 1) : kSdfChunk);
+    const size_t R = 2 * (size_t)P.m_max;
+    Bump b(ws);
+    int maxw = 0;
+    for (int l = 0; l < L; ++l) {
+        const size_t wn = (size_t)d->layers[l].out_dim * d->layers[l].in_dim;
+        P.W[l] = b.take(wn);
+        P.dW[l] = b.take(wn);
+        P.db[l] = b.take(d->layers[l].out_dim);
+        P.IN[l] = b.take(R * d->layers[l].in_dim);
+        P.Z[l] = l + 1 < L ? b.take(R * d->layers[l].out_dim) : nullptr;
+        maxw = max(maxw, max(d->layers[l].out_dim, d->layers[l].in_dim));
+    }
+    P.dZ = b.take(R * maxw);
+    P.dX = b.take(R * maxw);
+    P.bytes = b.off + 256;
+    return IRON_OK;
+}
+
+static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n, const float* d_sdf, const float* d_feat, const float* d_grad,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    SdfPlan P;
+    TR_TRY(sdf_plan(d, n, ws, P));
+    if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
+    rocblas_handle h = blas_for_current_device();
+    if (!h) return IRON_ERR_HIP;
+    TR_BLAS(rocblas_set_stream(h, st));
+    const int L = P.L, D0 = 3 + 6 * d->multires;
+    const iron_train_layer* ly = d->layers;
+    const float rs2 = 0.70710678118654752440f;
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_wn_fold, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, ly[l].out_dim, ly[l].in_dim, P.W[l]);
+        TR_HIP(hipMemsetAsync(P.db[l], 0, sizeof(float) * ly[l].out_dim, st));
+        if (n == 0) TR_HIP(hipMemsetAsync(P.dW[l], 0, sizeof(float) * ly[l].out_dim * ly[l].in_dim, st));
+    }
+    const int tangent = d_grad ? 1 : 0;
+    for (int64_t p0 = 0; p0 < n; p0 += P.m_max) {
+        const int m = (int)((n - p0) < P.m_max ? (n - p0) : P.m_max);
+        const int R = tangent ? 2 * m : m;
+        // forward, keeping every layer's input and pre-activation
+        hipLaunchKernelGGL(k_sdf_in, grid1((int64_t)m * D0), dim3(256), 0, st, x + 3 * p0, d_grad ? d_grad + 3 * p0 : nullptr, m, d->multires, P.IN[0]);
+        for (int l = 0; l + 1 < L; ++l) {
+            const int out = ly[l].out_dim, in = ly[l].in_dim, in_next = ly[l + 1].in_dim;
+            TR_TRY(gemm_rm(h, false, true, R, out, in, P.IN[l], in, P.W[l], in, 0.0f, P.Z[l], out));
+            const bool to_skip = (l + 1 == d->skip_layer);
+            hipLaunchKernelGGL(k_sdf_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, tangent, to_skip ? rs2 : 1.0f,
+                               P.IN[l + 1], in_next);
+            if (to_skip)
+                hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)R * D0), dim3(256), 0, st, P.IN[0], D0, R, D0, rs2, P.IN[l + 1], in_next, out);
+        }
+        // reverse
+        const int out_last = ly[L - 1].out_dim;
+        hipLaunchKernelGGL(k_sdf_seed, grid1((int64_t)m * out_last), dim3(256), 0, st, d_sdf ? d_sdf + p0 : nullptr,
+                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ);
+        for (int l = L - 1; l >= 0; --l) {
+            const int out = ly[l].out_dim, in = ly[l].in_dim;
+            TR_TRY(gemm_rm(h, true, false, out, in, R, P.dZ, out, P.IN[l], in, p0 == 0 ? 0.0f : 1.0f, P.dW[l], in));
+            hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
+            if (l == 0) break;
+            TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
+            const int outp = ly[l - 1].out_dim;
+            hipLaunchKernelGGL(k_sdf_act_back, grid1((int64_t)m * outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, tangent,
+                               l == d->skip_layer ? rs2 : 1.0f, P.dZ);
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_wn_back, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, P.dW[l], ly[l].out_dim, ly[l].in_dim,
+                           ly[l].d_weight_v, ly[l].d_weight_g);
+        TR_HIP(hipMemcpyAsync(ly[l].d_bias, P.db[l], sizeof(float) * ly[l].out_dim, hipMemcpyDeviceToDevice, st));
+    }
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
+// ---- RenderingNetwork -----------------------------------------------------------------------------------------------------------
+struct RenderIn {
+    int np, nv, nn, nf, D0, Lp, Lv;
+};
+static int render_in(const iron_render_train_desc* d, RenderIn& r) {
+    const bool use_v = d->mode == IRON_MODE_IDR || d->mode == IRON_MODE_NO_NORMAL;
+    const bool use_n = d->mode == IRON_MODE_IDR || d->mode == IRON_MODE_NO_VIEW_DIR;
+    if (d->mode < 0 || d->mode > 3) return IRON_ERR_BAD_ARG;
+    r.Lp = d->multires > 0 ? d->multires : 0;
+    r.Lv = d->multires_view > 0 ? d->multires_view : 0;
+    r.np = 3 + 6 * r.Lp;
+    r.nv = use_v ? 3 + 6 * r.Lv : 0;
+    r.nn = use_n ? 3 : 0;
+    r.nf = d->d_feature;
+    r.D0 = r.np + r.nv + r.nn + r.nf;
+    return IRON_OK;
+}
+
+__global__ void k_render_in(RenderIn r, const float* __restrict__ pts, const float* __restrict__ nrm, const float* __restrict__ view,
+                            const float* __restrict__ feat, int m, float* __restrict__ in0) {
+    GRID_STRIDE(i, (int64_t)m * r.D0) {
+        const int p = (int)(i / r.D0);
+        int c = (int)(i % r.D0);
+        float dv; int comp;
+        float val;
+        if (c < r.np) val = pe_col(pts + 3 * (size_t)p, c, &dv, &comp);
+        else if ((c -= r.np) < r.nv) val = pe_col(view + 3 * (size_t)p, c, &dv, &comp);
+        else if ((c -= r.nv) < r.nn) val = nrm[3 * (size_t)p + c];
+        else val = feat[(size_t)p * r.nf + (c - r.nn)];
+        in0[i] = val;
+    }
+}
+
+// one thread per point: fold dL/d(in0) back onto points / view_dirs / normals
+__global__ void k_render_in_back(RenderIn r, const float* __restrict__ pts, const float* __restrict__ view, int m, const float* __restrict__ din0,
+                                 float* __restrict__ d_pts, float* __restrict__ d_view, float* __restrict__ d_nrm) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const float* g = din0 + (size_t)p * r.D0;
+    if (d_pts) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < r.np; ++c) { float dv; int comp; pe_col(pts + 3 * (size_t)p, c, &dv, &comp); acc[comp] += g[c] * dv; }
+        for (int k = 0; k < 3; ++k) d_pts[3 * (size_t)p + k] = acc[k];
+    }
+    if (d_view) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < r.nv; ++c) { float dv; int comp; pe_col(view + 3 * (size_t)p, c, &dv, &comp); acc[comp] += g[r.np + c] * dv; }
+        for (int k = 0; k < 3; ++k) d_view[3 * (size_t)p + k] = acc[k];
+    }
+    if (d_nrm)
+        for (int k = 0; k < 3; ++k) d_nrm[3 * (size_t)p + k] = r.nn ? g[r.np + r.nv + k] : 0.0f;
+}
+
+__global__ void k_relu_act(float* __restrict__ Z, const float* __restrict__ bias, int m, int out, float sc, float* __restrict__ next, int ld_next) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int p = (int)(i / out), c = (int)(i % out);
+        const float z = Z[i] + bias[c];
+        Z[i] = z;
+        next[(size_t)p * ld_next + c] = fmaxf(z, 0.0f) * sc;
+    }
+}
+
+__global__ void k_relu_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, float sc, float* __restrict__ dZ) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int p = (int)(i / out), c = (int)(i % out);
+        dZ[i] = Z[i] > 0.0f ? dX[(size_t)p * ld_dx + c] * sc : 0.0f;
+    }
+}
+
+// last layer: z = Z + b; y = os (z + ob); optionally sq * sigmoid(y); dZ = dL/dz
+__global__ void k_render_out_back(const float* __restrict__ Z, const float* __restrict__ bias, const float* __restrict__ d_out, int m, int out, float ob,
+                                  float os, int squeeze, float sq, float* __restrict__ dZ) {
+    GRID_STRIDE(i, (int64_t)m * out) {
+        const int c = (int)(i % out);
+        float g = d_out[i];
+        if (squeeze) {
+            const float y = os * ((Z[i] + bias[c]) + ob);
+            const float s = 1.0f / (1.0f + expf(-y));
+            g *= sq * s * (1.0f - s);
+        }
+        dZ[i] = g * os;
+    }
+}
+
+constexpr int kRenderChunk = 131072;
+
+struct RenderPlan {
+    int L, m_max;
+    RenderIn in;
+    float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *X[kMaxLayers], *Z[kMaxLayers];
+    float *dZ, *dX, *dIN0;
+    size_t bytes;
+};
+
+static int render_plan(const iron_render_train_desc* d, int64_t n, void* ws, RenderPlan& P) {
+    if (!d || !d->layers || d->n_linear < 1 || d->n_linear > kMaxLayers || d->d_feature < 0) return IRON_ERR_BAD_ARG;
+    TR_TRY(render_in(d, P.in));
+    const int L = d->n_linear;
+    if (d->layers[0].in_dim != P.in.D0 || d->layers[L - 1].out_dim != d->d_out) return IRON_ERR_UNSUPPORTED;
+    for (int l = 1; l < L; ++l)
+        if (d->layers[l].in_dim != d->layers[l - 1].out_dim + (l == d->skip_layer ? P.in.D0 : 0)) return IRON_ERR_UNSUPPORTED;
+    if (d->skip_layer == 0) return IRON_ERR_UNSUPPORTED;
+    P.L = L;
+    P.m_max = (int)(n < kRenderChunk ? (n > 0 ? n : 1) : kRenderChunk);
+    const size_t R = (size_t)P.m_max;
+    Bump b(ws);
+    int maxw = P.in.D0;
+    for (int l = 0; l < L; ++l) {
+        const size_t wn = (size_t)d->layers[l].out_dim * d->layers[l].in_dim;
+        P.W[l] = b.take(wn);
+        P.dW[l] = b.take(wn);
+        P.db[l] = b.take(d->layers[l].out_dim);
+        P.X[l] = b.take(R * d->layers[l].in_dim);
+        P.Z[l] = b.take(R * d->layers[l].out_dim);
+        maxw = max(maxw, max(d->layers[l].out_dim, d->layers[l].in_dim));
+    }
+    P.dZ = b.take(R * maxw);
+    P.dX = b.take(R * maxw);
+    P.dIN0 = b.take(R * P.in.D0);
+    P.bytes = b.off + 256;
+    return IRON_OK;
+}
+
+static int render_backward(const iron_render_train_desc* d, const float* pts, const float* nrm, const float* view, const float* feat, int64_t n,
+                           const float* d_out, float* d_pts, float* d_nrm, float* d_view, float* d_feat, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    RenderPlan P;
+    TR_TRY(render_plan(d, n, ws, P));
+    if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
+    const RenderIn& I = P.in;
+    if (n > 0 && (!pts || !d_out || (I.nf && !feat) || (I.nn && !nrm) || (I.nv && !view))) return IRON_ERR_BAD_ARG;
+    rocblas_handle h = blas_for_current_device();
+    if (!h) return IRON_ERR_HIP;
+    TR_BLAS(rocblas_set_stream(h, st));
+    const int L = P.L;
+    const iron_train_layer* ly = d->layers;
+    const float rs2 = 0.70710678118654752440f;
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_wn_fold, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, ly[l].out_dim, ly[l].in_dim, P.W[l]);
+        TR_HIP(hipMemsetAsync(P.db[l], 0, sizeof(float) * ly[l].out_dim, st));
+        if (n == 0) TR_HIP(hipMemsetAsync(P.dW[l], 0, sizeof(float) * ly[l].out_dim * ly[l].in_dim, st));
+    }
+    for (int64_t p0 = 0; p0 < n; p0 += P.m_max) {
+        const int m = (int)((n - p0) < P.m_max ? (n - p0) : P.m_max);
+        const float* cp = pts + 3 * p0;
+        const float* cv = view ? view + 3 * p0 : nullptr;
+        hipLaunchKernelGGL(k_render_in, grid1((int64_t)m * I.D0), dim3(256), 0, st, I, cp, nrm ? nrm + 3 * p0 : nullptr, cv,
+                           feat ? feat + (size_t)p0 * I.nf : nullptr, m, P.X[0]);
+        for (int l = 0; l < L; ++l) {
+            const int out = ly[l].out_dim, in = ly[l].in_dim;
+            TR_TRY(gemm_rm(h, false, true, m, out, in, P.X[l], in, P.W[l], in, 0.0f, P.Z[l], out));
+            if (l + 1 == L) break;
+            const bool to_skip = (l + 1 == d->skip_layer);
+            const int in_next = ly[l + 1].in_dim;
+            hipLaunchKernelGGL(k_relu_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, to_skip ? rs2 : 1.0f, P.X[l + 1], in_next);
+            if (to_skip)
+                hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.X[0], I.D0, m, I.D0, rs2, P.X[l + 1], in_next, out);
+        }
+        const int out_last = ly[L - 1].out_dim;
+        hipLaunchKernelGGL(k_render_out_back, grid1((int64_t)m * out_last), dim3(256), 0, st, P.Z[L - 1], ly[L - 1].bias, d_out + (size_t)p0 * out_last, m,
+                           out_last, d->output_bias, d->output_scale, d->squeeze_out, d->squeeze_out_scale, P.dZ);
+        TR_HIP(hipMemsetAsync(P.dIN0, 0, sizeof(float) * (size_t)m * I.D0, st));
+        for (int l = L - 1; l >= 0; --l) {
+            const int out = ly[l].out_dim, in = ly[l].in_dim;
+            TR_TRY(gemm_rm(h, true, false, out, in, m, P.dZ, out, P.X[l], in, p0 == 0 ? 0.0f : 1.0f, P.dW[l], in));
+            hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
+            TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
+            if (l == 0) {
+                hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, 0, m, I.D0, 1.0f, P.dIN0, I.D0);
+                break;
+            }
+            const int outp = ly[l - 1].out_dim;
+            const bool is_skip = (l == d->skip_layer);
+            if (is_skip) hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, outp, m, I.D0, rs2, P.dIN0, I.D0);
+            hipLaunchKernelGGL(k_relu_back, grid1((int64_t)m * outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ);
+        }
+        hipLaunchKernelGGL(k_render_in_back, dim3((m + 255) / 256), dim3(256), 0, st, I, cp, cv, m, P.dIN0, d_pts ? d_pts + 3 * p0 : nullptr,
+                           (d_view && I.nv) ? d_view + 3 * p0 : nullptr, d_nrm ? d_nrm + 3 * p0 : nullptr);
+        if (d_view && !I.nv) TR_HIP(hipMemsetAsync(d_view + 3 * p0, 0, sizeof(float) * 3 * m, st));
+        if (d_feat && I.nf)
+            hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)m * I.nf), dim3(256), 0, st, P.dIN0 + (I.np + I.nv + I.nn), I.D0, m, I.nf, 1.0f,
+                               d_feat + (size_t)p0 * I.nf, I.nf, 0);
+    }
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_wn_back, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, P.dW[l], ly[l].out_dim, ly[l].in_dim,
+                           ly[l].d_weight_v, ly[l].d_weight_g);
+        TR_HIP(hipMemcpyAsync(ly[l].d_bias, P.db[l], sizeof(float) * ly[l].out_dim, hipMemcpyDeviceToDevice, st));
+    }
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
+// ---- GGX (models/renderer_ggx.py:82-146): first-order dual numbers in (cos, alpha, distance) -------------------------------------
+struct D3 {
+    float v, d[3];
+};
+__device__ __forceinline__ D3 cst(float c) { return {c, {0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D3 var(float x, int k) { D3 r = {x, {0.f, 0.f, 0.f}}; r.d[k] = 1.0f; return r; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__device__ __forceinline__ D3 operator*(D3 a, D3 b) {
+    return {a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+__device__ __forceinline__ D3 operator/(D3 a, D3 b) {
+    const float q = a.v / b.v, ib = 1.0f / b.v;
+    return {q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib}};
+}
+__device__ __forceinline__ D3 dsqrt(D3 a) {
+    const float s = sqrtf(a.v), k = 0.5f / s;
+    return {s, {a.d[0] * k, a.d[1] * k, a.d[2] * k}};
+}
+
+__global__ void k_ggx_back(float light, const float* __restrict__ dist, const float* __restrict__ nrm, const float* __restrict__ view,
+                           const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ rough,
+                           const float* __restrict__ tab_trans, const float* __restrict__ tab_diff, int n, const float* __restrict__ g_diff,
+                           const float* __restrict__ g_spec, const float* __restrict__ g_rgb, float* __restrict__ d_light,
+                           float* __restrict__ d_dist, float* __restrict__ d_nrm, float* __restrict__ d_view, float* __restrict__ d_kd,
+                           float* __restrict__ d_ks, float* __restrict__ d_rough) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float light_acc = 0.0f;
+    if (p < n) {
+        const float* nn = nrm + 3 * (size_t)p;
+        const float* vv = view + 3 * (size_t)p;
+        const float raw_dot = (vv[0] * nn[0] + vv[1] * nn[1]) + vv[2] * nn[2];
+        const float cdot = fminf(fmaxf(raw_dot, 0.00001f), 0.99999f);
+        const bool dot_live = raw_dot >= 0.00001f && raw_dot <= 0.99999f;  // torch.clamp passes the gradient on [min, max]
+        const float r0 = rough[p];
+        const float alpha0 = fmaxf(r0, 0.0001f);
+        const bool alpha_live = r0 >= 0.0001f;
+        const float pi_f = 3.14159274101257324219f;
+        const float m_inv_eta2 = (float)(1.0 / (1.48958738 * 1.48958738));
+        // piecewise-constant table factors
+        const long long tx = (long long)floorf(powf(cdot, 0.25f) * 100.0f);
+        const long long ty = (long long)floorf(powf(alpha0 / 4.0f, 0.25f) * 50.0f);
+        long long ti = ty * 100 + tx;
+        ti = ti < 0 ? 0 : (ti > 4999 ? 4999 : ti);
+        const float T12 = fminf(fmaxf(tab_trans[ti], 0.0f), 1.0f);
+        const long long ai = ty < 0 ? 0 : (ty > 49 ? 49 : ty);
+        const float Fdr = fminf(fmaxf(1.0f - tab_diff[ai], 0.0f), 1.0f);
+        const float fd = 1.0f - Fdr + 1e-10f;
+
+        const D3 c = var(cdot, 0), a = var(alpha0, 1), ds = var(dist[p], 2);
+        const D3 unit = cst(1.0f) / (ds * ds + cst(1e-10f));  // intensity per unit light
+        const D3 c2 = c * c;
+        const D3 a2 = a * a;
+        const D3 root = c2 + (cst(1.0f) - c2) / (a2 + cst(1e-10f));
+        const D3 Dm = cst(1.0f) / (cst(pi_f) * a2 * root * root + cst(1e-10f));
+        const D3 tan_t = dsqrt(cst(1.0f) - c2) / (c + cst(1e-10f));
+        const D3 rt = a * tan_t;
+        const D3 g1 = cst(2.0f) / (cst(1.0f) + dsqrt(rt * rt + cst(1.0f)));
+        const D3 Ks = unit * cst(0.03867f) * Dm * (g1 * g1) / (cst(4.0f) * c + cst(1e-10f));  // specular per unit light and albedo
+        const D3 Kd = unit * c * cst(T12 * T12 * m_inv_eta2 / (fd * pi_f));                 // diffuse  per unit light and albedo
+        float A = 0.0f, B = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gd = (g_diff ? g_diff[3 * (size_t)p + k] : 0.0f) + (g_rgb ? g_rgb[3 * (size_t)p + k] : 0.0f);
+            const float gs = (g_spec ? g_spec[3 * (size_t)p + k] : 0.0f) + (g_rgb ? g_rgb[3 * (size_t)p + k] : 0.0f);
+            if (d_kd) d_kd[3 * (size_t)p + k] = gd * light * Kd.v;
+            if (d_ks) d_ks[3 * (size_t)p + k] = gs * light * Ks.v;
+            A += gd * kd[3 * (size_t)p + k];
+            B += gs * ks[3 * (size_t)p + k];
+        }
+        light_acc = A * Kd.v + B * Ks.v;
+        const float dc = dot_live ? light * (A * Kd.d[0] + B * Ks.d[0]) : 0.0f;
+        if (d_rough) d_rough[p] = alpha_live ? light * (A * Kd.d[1] + B * Ks.d[1]) : 0.0f;
+        if (d_dist) d_dist[p] = light * (A * Kd.d[2] + B * Ks.d[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (d_nrm) d_nrm[3 * (size_t)p + k] = dc * vv[k];
+            if (d_view) d_view[3 * (size_t)p + k] = dc * nn[k];
+        }
+    }
+    if (d_light) {
+        for (int o = 32; o > 0; o >>= 1) light_acc += __shfl_xor(light_acc, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(d_light, light_acc);
+    }
+}
+
+}  // namespace iron_train
+
+using namespace iron_train;
+
+extern "C" int iron_train_last_hip_error(void) { return g_hip_error; }
+extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }
+
+extern "C" size_t iron_sdf_backward_workspace_bytes(const iron_sdf_train_desc* desc, int64_t n) {
+    SdfPlan P;
+    if (n < 0 || sdf_plan(desc, n, nullptr, P) != IRON_OK) return 0;
+    return P.bytes;
+}
+
+extern "C" int iron_sdf_backward(const iron_sdf_train_desc* desc, const float* x, int64_t n, const float* d_sdf, const float* d_feature,
+                                 const float* d_gradient, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || !workspace || (n > 0 && !x)) return IRON_ERR_BAD_ARG;
+    return sdf_backward(desc, x, n, d_sdf, d_feature, d_gradient, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t iron_render_backward_workspace_bytes(const iron_render_train_desc* desc, int64_t n) {
+    RenderPlan P;
+    if (n < 0 || render_plan(desc, n, nullptr, P) != IRON_OK) return 0;
+    return P.bytes;
+}
+
+extern "C" int iron_render_backward(const iron_render_train_desc* desc, const float* points, const float* normals, const float* view_dirs,
+                                    const float* features, int64_t n, const float* d_out, float* d_points, float* d_normals, float* d_view_dirs,
+                                    float* d_features, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || !workspace) return IRON_ERR_BAD_ARG;
+    return render_backward(desc, points, normals, view_dirs, features, n, d_out, d_points, d_normals, d_view_dirs, d_features, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int iron_ggx_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
+                                           const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                                           const float* tab_trans, const float* tab_diff, int64_t n, const float* d_diffuse_rgb,
+                                           const float* d_specular_rgb, const float* d_rgb, float* d_light, float* d_distance, float* d_normal,
+                                           float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo, float* d_roughness, void* stream) {
+    if (n < 0) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_light) TR_HIP(hipMemsetAsync(d_light, 0, sizeof(float), st));
+    if (n == 0) return IRON_OK;
+    if (!distance || !normal || !viewdir || !diffuse_albedo || !specular_albedo || !roughness || !tab_trans || !tab_diff) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_ggx_back, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, light, distance, normal, viewdir, diffuse_albedo, specular_albedo,
+                       roughness, tab_trans, tab_diff, (int)n, d_diffuse_rgb, d_specular_rgb, d_rgb, d_light, d_distance, d_normal, d_viewdir,
+                       d_diffuse_albedo, d_specular_albedo, d_roughness);
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}

@@ -188,14 +188,19 @@ class SDFNetwork(_HipNet):
         return self.forward(x)
 
     def gradient(self, x: torch.Tensor) -> torch.Tensor:
-        """d sdf / dx (fields.py:106-118), value only: no autograd graph is attached."""
-        return self.get_all(x, is_training=False)[2]
+        """d sdf / dx (fields.py:106-118).  Under grad mode with trainable parameters the result is attached to them (the
+        reference's create_graph=True; this is what its eikonal loss differentiates), otherwise values only."""
+        from .autograd import any_requires_grad
+        return self.get_all(x, is_training=any_requires_grad(*self.parameters()))[2]
 
     def get_all(self, x: torch.Tensor, is_training: bool = True):
         """sdf [...,1], feature [...,d_out-1], gradient [...,3]  (fields.py:120-137)."""
         if is_training:
-            raise NotImplementedError("iron_amd builds the forward render path only (is_training=False); "
-                                      "autograd through the HIP kernels is SURVEY 8 row f-2")
+            # attached to the parameters (to second order through the gradient): HIP forward + iron_sdf_backward
+            from .autograd import SDFGetAllFn, _layer_params
+            sh = list(x.shape[:-1])
+            sdf, feat, grad = SDFGetAllFn.apply(self, x.detach().reshape(-1, 3), *_layer_params(self))
+            return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])
         xx = _lib.require_cuda_f32(x.detach(), "x")
         sh = list(xx.shape[:-1])
         xx = xx.reshape(-1, 3)
@@ -277,7 +282,15 @@ class RenderingNetwork(_HipNet):
         return d
 
     def forward(self, points, normals, view_dirs, feature_vectors) -> torch.Tensor:
-        """[...,3] x3 (+ [...,d_feature]) -> [..., d_out]  (fields.py:203-239)."""
+        """[...,3] x3 (+ [...,d_feature]) -> [..., d_out]  (fields.py:203-239).  Differentiable (inputs and parameters) when
+        called under grad mode with anything that requires grad: HIP forward + iron_render_backward."""
+        from .autograd import RenderNetFn, _layer_params, any_requires_grad
+        params = _layer_params(self)
+        if any_requires_grad(points, normals, view_dirs, feature_vectors, *params):
+            return RenderNetFn.apply(self, points, normals, view_dirs, feature_vectors, *params)
+        return self._forward_values(points, normals, view_dirs, feature_vectors)
+
+    def _forward_values(self, points, normals, view_dirs, feature_vectors) -> torch.Tensor:
         p = _lib.require_cuda_f32(points.detach(), "points")
         sh = list(p.shape[:-1])
         p = p.reshape(-1, 3)

@@ -434,15 +434,22 @@ def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_ho
     return results
 
 
+def reparam_points(nondiff_points, nondiff_grads, nondiff_trgt_dirs, diff_sdf_vals):
+    """raytracer.py:17-24: the tracer's (non-differentiable) hit point as a function of the SDF parameters."""
+    dot = (nondiff_grads * nondiff_trgt_dirs).sum(dim=-1, keepdim=True)
+    dot = torch.clamp(dot, min=1e-4)
+    return nondiff_points - nondiff_trgt_dirs / dot * (diff_sdf_vals - diff_sdf_vals.detach())
+
+
 def render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=False, max_num_pts=320000):
     """raytracer.py:593-662; mutates `results`.  With the GGX render_fn of iron_amd.rendering_func the whole
     body (get_all -> normalise -> materials -> GGX -> scatter) is one fused kernel launch; any other callable
-    gets the reference's generic gather / get_all / render_fn / reshape flow (chunked by max_num_pts)."""
-    if is_training:
-        raise NotImplementedError("is_training=True (autograd through the HIP kernels) is SURVEY 8 row f-2")
+    gets the reference's generic gather / get_all / render_fn / reshape flow (chunked by max_num_pts).
+    is_training=True takes the generic flow under grad mode: get_all attached to the SDF parameters,
+    reparam_points, render_fn over the differentiable HIP operators (iron_amd.autograd)."""
     dots_sh = list(results["convergent_mask"].shape)
     fused = getattr(render_fn, "iron_fused_ggx", None)
-    if fused is not None:
+    if fused is not None and not is_training:
         out = fused(results, sdf_network, color_network_dict)
         for k, v in out.items():
             v = v.reshape(dots_sh + [-1])
@@ -457,11 +464,13 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
             torch.split(results["convergent_mask"].reshape(-1), max_num_pts, dim=0)):
         if mask_split.any():
             points_split, ray_d_split, ray_o_split = points_split[mask_split], ray_d_split[mask_split], ray_o_split[mask_split]
-            _, feature_split, normal_split = sdf_network.get_all(points_split, is_training=False)
+            sdf_split, feature_split, normal_split = sdf_network.get_all(points_split, is_training=is_training)
+            if is_training:
+                points_split = reparam_points(points_split, normal_split.detach(), -ray_d_split.detach(), sdf_split)
         else:
             e = torch.zeros(0, dtype=torch.float32, device=points_split.device)
             points_split = ray_d_split = ray_o_split = normal_split = feature_split = e
-        with torch.no_grad():
+        with torch.set_grad_enabled(is_training):
             r = render_fn(mask_split, color_network_dict, ray_o_split, ray_d_split, points_split, normal_split,
                           feature_split)
         if merge is None:

@@ -47,7 +47,17 @@ class GGXColocatedRenderer(nn.Module):
 
     def forward(self, light, distance, normal, viewdir, params={}):
         """light: scalar; distance [...,1]; normal, viewdir [...,3]; params: diffuse_albedo [...,3],
-        specular_albedo [...,3], specular_roughness [...,1] -> diffuse_rgb, specular_rgb, rgb [...,3]."""
+        specular_albedo [...,3], specular_roughness [...,1] -> diffuse_rgb, specular_rgb, rgb [...,3].
+        Differentiable under grad mode (HIP forward + iron_ggx_colocated_backward)."""
+        from .autograd import GGXColocatedFn, any_requires_grad
+        kd, ks, al = params["diffuse_albedo"], params["specular_albedo"], params["specular_roughness"]
+        if any_requires_grad(light, distance, normal, viewdir, kd, ks, al):
+            d, s, rgb = GGXColocatedFn.apply(self, light, distance, normal, viewdir, kd, ks, al)
+            return {"diffuse_rgb": d, "specular_rgb": s, "rgb": rgb}
+        return self._forward_values(float(light), distance, normal, viewdir, kd, ks, al)
+
+    def _forward_values(self, light, distance, normal, viewdir, kd, ks, al):
+        params = {"diffuse_albedo": kd, "specular_albedo": ks, "specular_roughness": al}
         nrm = _lib.require_cuda_f32(normal.detach(), "normal")
         sh = list(nrm.shape[:-1])
         nrm = nrm.reshape(-1, 3)
