@@ -486,13 +486,18 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
 def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=False):
     """raytracer.py:665-729: one ray on each side of every edge pixel, blended by the area the edge cuts off
     the (circular, r = 0.707) pixel; mutates `results`."""
-    if is_training:
-        raise NotImplementedError("is_training=True (autograd through the HIP kernels) is SURVEY 8 row f-2")
     edge_points, edge_uv, edge_pixel_idx = results["edge_points"], results["edge_uv"], results["edge_pixel_idx"]
     edge_pixel_center = torch.floor(edge_uv) + 0.5
 
-    _, edge_grads = sdf_network.get_sdf_and_gradient(edge_points)
-    edge_normals = edge_grads / (edge_grads.norm(dim=-1, keepdim=True) + 1e-10)
+    if is_training:
+        # row f-2: the edge point moves with the SDF parameters along its normal, so the blend weight is in the graph
+        edge_sdf, _, edge_grads = sdf_network.get_all(edge_points, is_training=True)
+    else:
+        _, edge_grads = sdf_network.get_sdf_and_gradient(edge_points)
+    edge_normals = edge_grads.detach() / (edge_grads.detach().norm(dim=-1, keepdim=True) + 1e-10)
+    if is_training:
+        edge_points = reparam_points(edge_points, edge_grads.detach(), edge_normals, edge_sdf)
+        edge_uv = camera.project(edge_points)
     edge_normals2d = torch.matmul(edge_normals, camera.W2C[:3, :3].transpose(1, 0))[:, :2]
     edge_normals2d = edge_normals2d / (edge_normals2d.norm(dim=-1, keepdim=True) + 1e-10)
 
@@ -526,8 +531,8 @@ def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_di
     results["normal"].view(-1, 3)[edge_pixel_idx] = edge_grads
     results["edge_pos_neg_normal"] = torch.cat([pos_side_results["normal"][pos_side_results["convergent_mask"]],
                                                 neg_side_results["normal"][neg_side_results["convergent_mask"]]], dim=0)
-    results["uv"].view(-1, 2)[edge_pixel_idx] = edge_uv
-    results["points"].view(-1, 3)[edge_pixel_idx] = edge_points
+    results["uv"].view(-1, 2)[edge_pixel_idx] = edge_uv.detach()
+    results["points"].view(-1, 3)[edge_pixel_idx] = edge_points.detach()
 
 
 def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes=False, handle_edges=True,

@@ -42,6 +42,65 @@ def sdf_get_all_train(sd: Dict[str, Tensor], spec: R.SDFSpec, x: Tensor):
     return y, feat, grad
 
 
+def render_normal_and_color_train(scene: R.Scene, res: Dict[str, Tensor]) -> None:
+    """render_normal_and_color(is_training=True), raytracer.py:593-662 (one chunk: the goldens are far below 320 000 points);
+    mutates `res`."""
+    sh = list(res["convergent_mask"].shape)
+    m = res["convergent_mask"].reshape(-1)
+    if bool(m.any()):
+        p = res["points"].reshape(-1, 3)[m]
+        d = res["ray_d"].reshape(-1, 3)[m]
+        o = res["ray_o"].reshape(-1, 3)[m]
+        sdf, feat, grad = sdf_get_all_train(scene.sdf_sd, scene.sdf_spec, p)
+        p = reparam_points(p, grad.detach(), -d.detach(), sdf)
+    else:
+        p = d = o = grad = feat = torch.zeros(0, dtype=torch.float32)
+    with torch.enable_grad():
+        r = R.render_fn_ggx(scene, m, o, d, p, grad, feat)
+    for k, v in r.items():
+        v = v.reshape(sh + [-1])
+        res[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+
+
+def render_edge_pixels_train(scene: R.Scene, results: Dict[str, Tensor], cam: R.CameraSpec, prm: R.TracerParams = R.TracerParams()) -> None:
+    """raytracer.py:665-729 with is_training=True: the edge point is re-parametrised along its normal, re-projected, and the
+    blend weight of the two side colours becomes a function of the SDF parameters; the side rays are shaded under grad."""
+    edge_points, edge_idx = results["edge_points"], results["edge_pixel_idx"]
+    center = torch.floor(results["edge_uv"]) + 0.5
+    edge_sdf, _, grads = sdf_get_all_train(scene.sdf_sd, scene.sdf_spec, edge_points)
+    nrm = grads.detach() / (grads.detach().norm(dim=-1, keepdim=True) + 1e-10)
+    edge_points = reparam_points(edge_points, grads.detach(), nrm, edge_sdf)
+    edge_uv = R.project(cam, edge_points)
+    n2d = torch.matmul(nrm, cam.W2C[:3, :3].transpose(1, 0))[:, :2]
+    n2d = n2d / (n2d.norm(dim=-1, keepdim=True) + 1e-10)
+    radius = 0.707
+    pos_uv, neg_uv = center - radius * n2d, center + radius * n2d
+    dot2d = torch.sum((edge_uv - center) * n2d, dim=-1)
+    alpha = 2 * torch.arccos(torch.clamp(dot2d / radius, min=0.0, max=1.0))
+    w_pos = 1.0 - (alpha - torch.sin(alpha)) / (2.0 * torch.pi)
+    with torch.no_grad():
+        pos = R.raytrace_pixels(scene, pos_uv, cam, prm=prm)
+        neg = R.raytrace_pixels(scene, neg_uv, cam, prm=prm)
+    render_normal_and_color_train(scene, pos)
+    render_normal_and_color_train(scene, neg)
+    color = pos["color"] * w_pos.unsqueeze(-1) + neg["color"] * (1.0 - w_pos.unsqueeze(-1))
+    results["color"].view(-1, 3)[edge_idx] = color
+    results["normal"].view(-1, 3)[edge_idx] = grads
+    results["uv"].view(-1, 2)[edge_idx] = edge_uv.detach()
+    results["points"].view(-1, 3)[edge_idx] = edge_points.detach()
+
+
+def render_camera_edges_train(scene: R.Scene, cam: R.CameraSpec, depth_edge_mask: Tensor) -> Dict[str, Tensor]:
+    """render_camera(fill_holes=False, handle_edges=True, is_training=True), raytracer.py:778-814, behind a given depth-edge
+    mask (the sobel stencil is the unpinned part, see oracle/iron_ref.py)."""
+    with torch.no_grad():
+        res = R.raytrace_camera_full(scene, cam, max_num_rays=50000, fill_holes=False, detect_edges=True, depth_edge_mask=depth_edge_mask)
+    render_normal_and_color_train(scene, res)
+    if res["edge_mask"].sum() > 0:
+        render_edge_pixels_train(scene, res, cam)
+    return res
+
+
 def render_camera_train(scene: R.Scene, cam: R.CameraSpec) -> Dict[str, Tensor]:
     """render_camera(fill_holes=False, handle_edges=False, is_training=True), raytracer.py:778-814: the trace runs without
     grad (raytracer.py:542 @torch.no_grad), shading with it.  `scene`'s state dicts must be leaf_state()s."""

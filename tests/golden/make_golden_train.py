@@ -20,7 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as MG  # noqa: E402
 
-from models.raytracer import RayTracer, render_camera  # noqa: E402  (reference)
+from models.raytracer import (RayTracer, locate_edge_points, raytrace_camera, render_camera, render_edge_pixels,  # noqa: E402  (reference)
+                              render_normal_and_color)
 from models.renderer_ggx import GGXColocatedRenderer  # noqa: E402
 
 npf = MG.npf
@@ -65,5 +66,58 @@ def main():
           "sdf lin0.weight_v grad norm", float(nets["sdf_network"].lin0.weight_v.grad.norm()))
 
 
+def store_grads(nets, out):
+    n_params = 0
+    for name in NETS:
+        for pname, p in nets[name].named_parameters():
+            assert p.grad is not None, (name, pname)
+            g = p.grad.reshape(-1).double().numpy()
+            key = "%s/%s" % (name, pname)
+            out["gnorm:" + key] = np.float64(np.linalg.norm(g))
+            out["gsample:" + key] = g[sample_idx(g.size)]
+            n_params += 1
+    return n_params
+
+
+def edges():
+    """G15: the same with silhouette edge sampling in the graph (render_camera(handle_edges=True, is_training=True), the
+    setting render_surface.py trains with): 96x96 view of S1, the depth-edge mask an INPUT as in G8 (kornia is absent, so
+    detect_edges itself cannot run in the reference), then the reference's locate_edge_points -> render_normal_and_color ->
+    render_edge_pixels, all with is_training=True."""
+    from oracle import iron_ref as R  # only for the unpinned sobel mask, exactly as make_golden.py does for G8
+    nets = MG.build_reference_networks("S1")
+    sdf_net = nets["sdf_network"]
+    tracer = RayTracer()
+    cam = MG.fixture_camera(96, 96)
+    fn = MG.make_render_fn(nets, GGXColocatedRenderer(use_cuda=False), torch.float32)
+    res = raytrace_camera(cam, sdf_net, tracer, max_num_rays=50000, fill_holes=False, detect_edges=False)
+    depth_edge_mask = (R.sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+    with torch.no_grad():
+        res.update(locate_edge_points(cam, res["points"], sdf_net, max_step=16, step_size=1e-3, dot_threshold=5e-2,
+                                      max_num_rays=50000, mask=depth_edge_mask))
+    res["convergent_mask"] &= ~res["edge_mask"]
+    render_normal_and_color(res, sdf_net, nets, fn, is_training=True, max_num_pts=320000)
+    _cuda = torch.Tensor.cuda  # empty-chunk branch of render_normal_and_color calls .cuda() (raytracer.py:627-633); see make_golden.py
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        render_edge_pixels(res, cam, sdf_net, tracer, nets, fn, is_training=True)
+    finally:
+        torch.Tensor.cuda = _cuda
+    gen = torch.Generator().manual_seed(33)
+    wt = torch.rand(96, 96, 3, generator=gen) - 0.3
+    loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
+    loss.backward()
+    out = {"K": npf(cam.K), "W2C": npf(cam.W2C), "W": np.int64(96), "H": np.int64(96), "loss_weights": npf(wt),
+           "loss": np.float64(loss.item()), "color": npf(res["color"]), "normal": npf(res["normal"]),
+           "convergent_mask": npf(res["convergent_mask"]), "edge_mask": npf(res["edge_mask"]),
+           "depth_edge_mask_input": npf(depth_edge_mask)}
+    n_params = store_grads(nets, out)
+    np.savez_compressed(os.path.join(HERE, "g15_train_edges_S1.npz"), **out)
+    print("G15 loss", loss.item(), "edge pixels", int(res["edge_mask"].sum()), "param tensors", n_params)
+
+
 if __name__ == "__main__":
-    main()
+    if "--edges" in sys.argv:
+        edges()
+    else:
+        main()

@@ -30,6 +30,43 @@ def test_library_exports_every_declared_symbol():
     assert lib.iron_shade_workspace_bytes(1000) > 0
 
 
+def test_training_library_exports_every_declared_symbol():
+    """include/iron_train.h <-> libiron_train.so (the backward passes; links rocBLAS, loads without a GPU)."""
+    from iron_amd import _lib, build
+    build.build()
+    lib = _lib.load_train()
+    hdr = open(os.path.join(ROOT, "include", "iron_train.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(iron_[a-z_0-9]+)\s*\(", hdr))
+    assert {"iron_sdf_backward", "iron_render_backward", "iron_ggx_colocated_backward"} <= declared
+    for name in sorted(declared):
+        assert hasattr(lib, name), "symbol %s is declared but not exported" % name
+        assert name in _lib.TRAIN_SYMBOLS, "symbol %s has no ctypes binding" % name
+    # argument validation / workspace sizing happen on the host
+    assert lib.iron_sdf_backward(None, None, -1, None, None, None, None, 0, None) == -1
+    layers = (_lib.iron_train_layer * 9)()
+    dims = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256), (257, 256)]
+    for l, (o, i) in zip(layers, dims):
+        l.out_dim, l.in_dim = o, i
+    d = _lib.iron_sdf_train_desc()
+    d.n_linear, d.multires, d.skip_layer, d.layers = 9, 6, 4, layers
+    per_point = lib.iron_sdf_backward_workspace_bytes(ctypes.byref(d), 65536) / 65536
+    assert 30e3 < per_point < 60e3            # ~37 KB of kept activations per point (+ the two gradient buffers)
+    d.skip_layer = 3                          # inconsistent with the layer shapes
+    assert lib.iron_sdf_backward_workspace_bytes(ctypes.byref(d), 16) == 0
+
+
+def test_autograd_wrappers_refuse_cpu_parameters():
+    """is_training=True has no eager path either: CPU parameters / tensors raise."""
+    from iron_amd import scenes
+    nets = scenes.build_networks("S0")
+    with pytest.raises(RuntimeError):
+        nets["sdf_network"].get_all(torch.zeros(4, 3), is_training=True)
+    z = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):
+        nets["diffuse_albedo_network"](z, z, z, torch.zeros(4, 256))
+
+
 def test_cpu_tensors_are_refused_not_computed():
     """No CPU fallback: the product path raises on CPU tensors."""
     from iron_amd import scenes, _lib
