@@ -61,6 +61,32 @@ static int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, int k, cons
     return IRON_OK;
 }
 
+// dW[out,in] = beta dW + dZ[R,out]^T X[R,in].  The output is one or two tiles while K = R is 10^5: a plain SGEMM runs it on a
+// handful of CUs, so K is split into kSplitK strided batches (partials in `partial`, [kSplitK, out*in]) that fill the chip and
+// are then summed; the < kSplitK leftover rows go through one small GEMM.
+constexpr int kSplitK = 64;
+
+__global__ void k_reduce_partials(const float* __restrict__ partial, int splits, int count, float beta, float* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * count + i];
+        dst[i] = beta != 0.0f ? beta * dst[i] + s : s;
+    }
+}
+
+static int gemm_dw(rocblas_handle h, hipStream_t st, int out, int in, int R, const float* dZ, const float* X, float beta, float* dW, float* partial) {
+    if (R < 64 * kSplitK) return gemm_rm(h, true, false, out, in, R, dZ, out, X, in, beta, dW, in);
+    const int kb = R / kSplitK;
+    const float one = 1.0f, zero = 0.0f;
+    TR_BLAS(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, in, out, kb, &one, X, in, (rocblas_stride)kb * in, dZ,
+                                          out, (rocblas_stride)kb * out, &zero, partial, in, (rocblas_stride)out * in, kSplitK));
+    const int count = out * in;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((count + 255) / 256), dim3(256), 0, st, partial, kSplitK, count, beta, dW);
+    const int done = kb * kSplitK;
+    if (R > done) return gemm_rm(h, true, false, out, in, R - done, dZ + (size_t)done * out, out, X + (size_t)done * in, in, 1.0f, dW, in);
+    return IRON_OK;
+}
+
 struct Bump {
     char* base;
     size_t off = 0;
@@ -227,7 +253,7 @@ constexpr int kMaxLayers = 16;
 struct SdfPlan {
     int L, m_max;
     float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *IN[kMaxLayers], *Z[kMaxLayers];
-    float *dZ, *dX;
+    float *dZ, *dX, *partial;
     size_t bytes;
 };
 
@@ -256,6 +282,7 @@ static int sdf_plan(const iron_sdf_train_desc* d, int64_t n, void* ws, SdfPlan& 
     }
     P.dZ = b.take(R * maxw);
     P.dX = b.take(R * maxw);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw);
     P.bytes = b.off + 256;
     return IRON_OK;
 }
@@ -297,7 +324,7 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
                            d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ);
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_rm(h, true, false, out, in, R, P.dZ, out, P.IN[l], in, p0 == 0 ? 0.0f : 1.0f, P.dW[l], in));
+            TR_TRY(gemm_dw(h, st, out, in, R, P.dZ, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
             hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
             if (l == 0) break;
             TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
@@ -405,7 +432,7 @@ struct RenderPlan {
     int L, m_max;
     RenderIn in;
     float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *X[kMaxLayers], *Z[kMaxLayers];
-    float *dZ, *dX, *dIN0;
+    float *dZ, *dX, *dIN0, *partial;
     size_t bytes;
 };
 
@@ -434,6 +461,7 @@ static int render_plan(const iron_render_train_desc* d, int64_t n, void* ws, Ren
     P.dZ = b.take(R * maxw);
     P.dX = b.take(R * maxw);
     P.dIN0 = b.take(R * P.in.D0);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw);
     P.bytes = b.off + 256;
     return IRON_OK;
 }
@@ -479,7 +507,7 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
         TR_HIP(hipMemsetAsync(P.dIN0, 0, sizeof(float) * (size_t)m * I.D0, st));
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_rm(h, true, false, out, in, m, P.dZ, out, P.X[l], in, p0 == 0 ? 0.0f : 1.0f, P.dW[l], in));
+            TR_TRY(gemm_dw(h, st, out, in, m, P.dZ, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
             hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
             TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
             if (l == 0) {

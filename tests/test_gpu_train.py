@@ -29,7 +29,9 @@ def _compare_param_grads(module, leaf_sd, tol, tag):
         r = _rel(p.grad.cpu().numpy(), ref.numpy())
         # a parameter whose gradient is pure rounding noise (e.g. zero-initialised PE columns' norm direction) is compared in
         # absolute terms against the largest gradient of the network
-        worst = max(worst, r)
+        if r > worst:
+            worst = r
+            _compare_param_grads.last = "%s |ref| %.2e" % (name, float(ref.norm()))
         assert r <= tol or float(ref.abs().max()) <= 1e-9, (tag, name, r)
         p.grad = None
     return worst
@@ -43,7 +45,7 @@ def test_sdf_get_all_backward_vs_autograd():
     nets = scenes.build_networks("S1")
     net = nets["sdf_network"].cuda()
     gen = torch.Generator().manual_seed(3)
-    for n, parts in ((301, "sfg"), (64, "g"), (64, "s"), (1, "sfg")):
+    for n, parts in ((301, "sfg"), (64, "g"), (64, "s"), (1, "sfg"), (5003, "sfg")):  # 5003: the split-K weight-gradient path
         x = torch.rand(n, 3, generator=gen) * 1.2 - 0.6
         a, B, Cc = torch.randn(n, 1, generator=gen), torch.randn(n, 256, generator=gen) * 0.1, torch.randn(n, 3, generator=gen)
         sd = T.leaf_state(cpu_sd(nets["sdf_network"]))
@@ -62,6 +64,54 @@ def test_sdf_get_all_backward_vs_autograd():
         l2.backward()
         w = _compare_param_grads(net, sd, 2e-4, "sdf n=%d %s" % (n, parts))
         print("sdf backward n=%d parts=%s worst rel-L2 %.2e" % (n, parts, w))
+
+
+def test_backward_is_additive_over_points_across_chunks():
+    """Size-independent property at sizes the oracle does not reach: the parameter gradient of a sum over points equals the sum
+    of the gradients of its parts.  70 001 SDF points span two 65 536-point chunks (weight gradients accumulated across
+    chunks, split-K inside each); 140 001 material points span two 131 072-point chunks."""
+    from iron_amd import scenes
+    nets = scenes.build_networks("S1")
+    sdf = nets["sdf_network"].cuda()
+    gen = torch.Generator().manual_seed(17)
+
+    def grads_of(mod, loss_fn, sl):
+        for p in mod.parameters():
+            p.grad = None
+        loss_fn(sl).backward()
+        return [p.grad.detach().clone() for p in mod.parameters()]
+
+    n = 70001
+    x = (torch.rand(n, 3, generator=gen) * 1.6 - 0.8).cuda()
+    a, B, Cc = torch.randn(n, 1, generator=gen).cuda(), (torch.randn(n, 256, generator=gen) * 0.05).cuda(), torch.randn(n, 3, generator=gen).cuda()
+
+    def sdf_loss(sl):
+        y, f, g = sdf.get_all(x[sl], is_training=True)
+        return (y * a[sl]).sum() + (f * B[sl]).sum() + (g * Cc[sl]).sum()
+
+    whole = grads_of(sdf, sdf_loss, slice(0, n))
+    h1 = grads_of(sdf, sdf_loss, slice(0, 30000))
+    h2 = grads_of(sdf, sdf_loss, slice(30000, n))
+    w = max(_rel(a_.cpu().numpy(), (b_ + c_).cpu().numpy()) for a_, b_, c_ in zip(whole, h1, h2))
+    print("sdf additivity over 2 chunks: worst rel-L2 %.2e" % w)
+    assert w <= 2e-5
+
+    net = nets["specular_albedo_network"].cuda()
+    n = 140001
+    pts = (torch.rand(n, 3, generator=gen) * 1.2 - 0.6).cuda()
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).cuda()
+    ft = (torch.randn(n, 256, generator=gen) * 0.3).cuda()
+    up = torch.randn(n, 3, generator=gen).cuda()
+
+    def mat_loss(sl):
+        return (net(pts[sl], nrm[sl], None, ft[sl]) * up[sl]).sum()
+
+    whole = grads_of(net, mat_loss, slice(0, n))
+    h1 = grads_of(net, mat_loss, slice(0, 50000))
+    h2 = grads_of(net, mat_loss, slice(50000, n))
+    w = max(_rel(a_.cpu().numpy(), (b_ + c_).cpu().numpy()) for a_, b_, c_ in zip(whole, h1, h2))
+    print("material additivity over 2 chunks: worst rel-L2 %.2e" % w)
+    assert w <= 2e-5
 
 
 def test_sdf_gradient_eikonal_term():
@@ -101,7 +151,7 @@ def test_render_network_backward_vs_autograd(name):
     sd = T.leaf_state(cpu_sd(mod))
     net = mod.cuda()
     gen = torch.Generator().manual_seed(11)
-    n = 517
+    n = 4517  # >= 4096 rows: the split-K weight-gradient path (with a ragged tail)
     ins = [torch.rand(n, 3, generator=gen) * 1.2 - 0.6, torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1),
            torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1), torch.randn(n, 256, generator=gen) * 0.3]
     use_view = mod.mode in ("idr", "no_normal")
@@ -120,9 +170,10 @@ def test_render_network_backward_vs_autograd(name):
             assert gpu_in[i].grad is None or float(gpu_in[i].grad.abs().max()) == 0.0, what
             continue
         r = _rel(gpu_in[i].grad.cpu().numpy(), cpu_in[i].grad.numpy())
+        print("   d/d%s rel-L2 %.2e" % (what, r))
         w = max(w, r)
         assert r <= 2e-4, (name, what, r)
-    print("%s backward worst rel-L2 %.2e" % (name, w))
+    print("%s backward worst rel-L2 %.2e (parameter side: %s)" % (name, w, getattr(_compare_param_grads, "last", "")))
 
 
 def test_ggx_backward_vs_autograd():
