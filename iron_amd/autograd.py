@@ -227,3 +227,13 @@ class GGXColocatedFn(torch.autograd.Function):
 
 def any_requires_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+def refuse_grad(what: str, *tensors) -> None:
+    """Operators without a backward must not hand detached results to a training graph."""
+    flat = []
+    for t in tensors:
+        flat += list(t.values()) if isinstance(t, dict) else [t]
+    if any_requires_grad(*flat):
+        raise NotImplementedError("%s has no backward pass in iron_amd (SURVEY 8 row f-2 covers SDFNetwork, RenderingNetwork and "
+                                  "GGXColocatedRenderer); call it under torch.no_grad() or on detached inputs" % what)

@@ -353,9 +353,11 @@ class NeRF(_HipNet):
         d.scale = 1.0
         return d
 
-    @torch.no_grad()
     def forward(self, input_pts, input_views):
-        """[...,4], [...,3] -> (alpha [...,1], rgb [...,3])  (fields.py:299-325)."""
+        """[...,4], [...,3] -> (alpha [...,1], rgb [...,3])  (fields.py:299-325).  Forward only: under grad mode with anything that
+        requires grad it raises instead of returning detached values."""
+        from .autograd import refuse_grad
+        refuse_grad("NeRF.forward", input_pts, input_views, *self.parameters())
         p = _lib.require_cuda_f32(input_pts.detach(), "input_pts")
         sh = list(p.shape[:-1])
         p = p.reshape(-1, 4)

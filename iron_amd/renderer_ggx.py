@@ -115,7 +115,9 @@ class CompositeRenderer(nn.Module):
         """params: diffuse_albedo, specular_albedo [...,3]; specular_roughness, metallic_eta, metallic_k, dielectric_eta
         [...,1] (+ metallic, dielectric, which the reference clamps and never uses; + env_light when use_env_light).
         Returns diffuse_rgb, specular_rgb, metallic_rgb, dielectric_rgb, rgb (+ env_light); as in the reference,
-        "diffuse_rgb" IS "rgb" (the same tensor: :847-853 add the specular term in place)."""
+        "diffuse_rgb" IS "rgb" (the same tensor: :847-853 add the specular term in place).  Forward only (no backward pass)."""
+        from .autograd import refuse_grad
+        refuse_grad("CompositeRenderer.forward", light, distance, normal, viewdir, params)
         nrm = _lib.require_cuda_f32(normal.detach(), "normal")
         sh = list(nrm.shape[:-1])
         nrm = nrm.reshape(-1, 3)
@@ -163,6 +165,8 @@ class _ColocHead(nn.Module):
         self.eta, self.k = 0.0, 0.0
 
     def forward(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha=None):
+        from .autograd import refuse_grad
+        refuse_grad(type(self).__name__ + ".forward", light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha)
         nrm = _lib.require_cuda_f32(normal.detach(), "normal")
         sh = list(nrm.shape[:-1])
         nrm = nrm.reshape(-1, 3)

@@ -112,12 +112,15 @@ def test_stage1_colour_network_with_skip():
                            multires=10, multires_view=4, squeeze_out=True).cuda()
     g = golden("g13_neus.npz")
     out = net(t(g["color_pts"]).cuda(), t(g["color_nrm"]).cuda(), t(g["color_view"]).cuda(), t(g["color_feat"]).cuda())
+    assert out.requires_grad  # like the reference module: attached to the parameters under grad mode (iron_amd.autograd)
+    out = out.detach()
     assert tuple(out.shape) == g["color_out"].shape
     err = np.abs(out.cpu().numpy() - g["color_out"]).max()
     print("stage-1 colour net: rel-L2 %.2e  max|d| %.2e" % (rel_l2(out.cpu().numpy(), g["color_out"]), err))
     assert rel_l2(out.cpu().numpy(), g["color_out"]) <= 1e-5
     for n in (1, 33):
-        o2 = net(t(g["color_pts"]).cuda()[:n], t(g["color_nrm"]).cuda()[:n], t(g["color_view"]).cuda()[:n], t(g["color_feat"]).cuda()[:n])
+        with torch.no_grad():
+            o2 = net(t(g["color_pts"]).cuda()[:n], t(g["color_nrm"]).cuda()[:n], t(g["color_view"]).cuda()[:n], t(g["color_feat"]).cuda()[:n])
         np.testing.assert_allclose(o2.cpu().numpy(), out[:n].cpu().numpy(), rtol=0, atol=1e-6)
 
 
@@ -138,7 +141,8 @@ def test_nerf_background_field():
     assert state_hash(nets) == golden_meta()["state_sha256_stage1"]
     g = golden("g13_neus.npz")
     nerf = nets["nerf"].cuda()
-    alpha, rgb = nerf(t(g["nerf_pts"]).cuda(), t(g["nerf_views"]).cuda())
+    with torch.no_grad():  # forward only: under grad mode NeRF.forward refuses rather than return detached values
+        alpha, rgb = nerf(t(g["nerf_pts"]).cuda(), t(g["nerf_views"]).cuda())
     assert tuple(alpha.shape) == g["nerf_alpha"].shape and tuple(rgb.shape) == g["nerf_rgb"].shape
     ra, rc = rel_l2(alpha.cpu().numpy(), g["nerf_alpha"]), rel_l2(rgb.cpu().numpy(), g["nerf_rgb"])
     print("NeRF: alpha rel-L2 %.2e  rgb rel-L2 %.2e" % (ra, rc))

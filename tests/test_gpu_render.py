@@ -46,17 +46,19 @@ def test_get_all_golden(s1):
         y2, f2, g2 = gpu["sdf_network"].get_all(x[:n], is_training=False)
         np.testing.assert_allclose(g2.cpu().numpy(), grad[:n].cpu().numpy(), rtol=0, atol=1e-6)
         np.testing.assert_allclose(f2.cpu().numpy(), feat[:n].cpu().numpy(), rtol=0, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        gpu["sdf_network"].get_all(x[:4], is_training=True)
+    # is_training=True: same values, attached to the parameters (row f-2; gradients are tests/test_gpu_train.py's job)
+    y3, f3, g3 = gpu["sdf_network"].get_all(x[:100], is_training=True)
+    assert y3.requires_grad and f3.requires_grad and g3.requires_grad
+    np.testing.assert_allclose(g3.detach().cpu().numpy(), grad[:100].cpu().numpy(), rtol=0, atol=1e-6)
 
 
 def test_material_networks_golden(s1):
     _, gpu = s1
     g = golden("g3_materials.npz")
     p, n, f = t(g["points"]).cuda(), t(g["normals"]).cuda(), t(g["features"]).cuda()
-    raw_d = gpu["diffuse_albedo_network"](p, n, -n, f).cpu().numpy()
-    raw_s = gpu["specular_albedo_network"](p, n, None, f).cpu().numpy()
-    raw_r = gpu["specular_roughness_network"](p, n, None, f).cpu().numpy()
+    raw_d = gpu["diffuse_albedo_network"](p, n, -n, f).detach().cpu().numpy()
+    raw_s = gpu["specular_albedo_network"](p, n, None, f).detach().cpu().numpy()
+    raw_r = gpu["specular_roughness_network"](p, n, None, f).detach().cpu().numpy()
     assert raw_d.shape == (256, 3) and raw_s.shape == (256, 3) and raw_r.shape == (256, 1)
     assert rel_l2(raw_d, g["raw_diffuse"]) <= 1e-5
     assert rel_l2(raw_s, g["raw_specular"]) <= 1e-5
@@ -64,7 +66,7 @@ def test_material_networks_golden(s1):
     m = get_materials(gpu, p, n, f)
     for k in ("diffuse_albedo", "specular_albedo", "specular_roughness"):
         assert m[k].shape == g[k].shape
-        assert rel_l2(m[k].cpu().numpy(), g[k]) <= 1e-5, k
+        assert rel_l2(m[k].detach().cpu().numpy(), g[k]) <= 1e-5, k
 
 
 def _render(scene, tag):
@@ -129,10 +131,31 @@ def test_generic_render_fn_path_matches_fused():
         np.testing.assert_allclose(res2[k].cpu().numpy(), res[k].cpu().numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
 
 
-def test_training_fails_loudly():
-    _, nets, cam, fn, _ = _render("S0", "c0")
+def test_training_mode_renders_the_same_image_attached_to_the_parameters():
+    _, nets, cam, fn, res0 = _render("S0", "c0")
+    res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, handle_edges=False, is_training=True)
+    assert res["color"].requires_grad and res["normal"].requires_grad
+    assert torch.equal(res["convergent_mask"], res0["convergent_mask"])
+    assert rel_l2(res["color"].detach().cpu().numpy(), res0["color"].cpu().numpy()) <= 2e-5  # generic operator chain vs the fused kernel
+
+
+def test_heads_without_a_backward_refuse_inputs_that_require_grad():
+    """Only the GGX path has a backward (row f-2): the composite / other BRDF heads and the NeRF field must not silently
+    return detached results inside a training graph."""
+    from iron_amd.fields import NeRF
+    from iron_amd.renderer_ggx import CompositeRenderer
+    z = torch.rand(8, 3, device="cuda")
+    nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True).cuda()
     with pytest.raises(NotImplementedError):
-        render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, handle_edges=False, is_training=True)
+        nerf(torch.rand(8, 4, device="cuda"), z)
+    with torch.no_grad():
+        nerf(torch.rand(8, 4, device="cuda"), z)
+    kd = torch.rand(8, 3, device="cuda", requires_grad=True)
+    one = torch.rand(8, 1, device="cuda")
+    params = {"diffuse_albedo": kd, "specular_albedo": z, "metallic": one, "dielectric": one, "specular_roughness": one * 0.3 + 0.05,
+              "metallic_eta": one + 1, "metallic_k": one + 2, "dielectric_eta": one + 1.2}
+    with pytest.raises(NotImplementedError):
+        CompositeRenderer(use_cuda=True)(5.0, one + 1, torch.nn.functional.normalize(z, dim=-1), torch.nn.functional.normalize(z, dim=-1), params=params)
 
 
 @pytest.mark.parametrize("seed,sigma,yaw", [(2, 0.008, 20.0), (3, 0.012, 135.0), (4, 0.016, 250.0)])
