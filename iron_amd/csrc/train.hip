@@ -159,16 +159,6 @@ __global__ void k_wn_back(const float* __restrict__ v, const float* __restrict__
     for (int c = lane; c < in; c += 64) dv[(size_t)r * in + c] = k1 * (dW[(size_t)r * in + c] - v[(size_t)r * in + c] * k2);
 }
 
-// out[c] += sum over `rows` rows of Z[:, c]   (out pre-zeroed; blocks of 256 rows, one atomic per column per block)
-__global__ void k_colsum(const float* __restrict__ Z, int rows, int cols, int ld, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
-    float s = 0.0f;
-    for (int r = r0; r < r1; ++r) s += Z[(size_t)r * ld + c];
-    atomicAdd(&out[c], s);
-}
-
 // ---- SDF network ----------------------------------------------------------------------------------------------------------------
 // rows [0,m): value; rows [m,2m): tangent along v (only when v != NULL)
 __global__ void k_sdf_in(const float* __restrict__ x, const float* __restrict__ v, int m, int L, float* __restrict__ in0) {
@@ -221,30 +211,49 @@ __global__ void k_add_cols(const float* __restrict__ src, int ld_src, int col0, 
     }
 }
 
-__global__ void k_sdf_seed(const float* __restrict__ d_sdf, const float* __restrict__ d_feat, int m, int out, int tangent, float* __restrict__ dZ) {
-    GRID_STRIDE(i, (int64_t)m * out) {
-        const int p = (int)(i / out), c = (int)(i % out);
-        dZ[i] = c == 0 ? (d_sdf ? d_sdf[p] : 0.0f) : (d_feat ? d_feat[(size_t)p * (out - 1) + c - 1] : 0.0f);
+// Column-strip form shared by the kernels that WRITE a layer's dZ: a thread owns column c of kStrip consecutive rows, so the
+// bias gradient (the column sum of the value rows of dZ) is accumulated on the way and costs one atomic per strip instead of
+// a second pass over dZ.
+constexpr int kStrip = 64;
+static inline dim3 strip_grid(int m, int out) { return dim3((out + 255) / 256, (m + kStrip - 1) / kStrip); }
+#define STRIP_PROLOGUE(m, out)                                  \
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;        \
+    if (c >= (out)) return;                                     \
+    const int r0 = blockIdx.y * kStrip, r1 = min((m), r0 + kStrip); \
+    float colsum = 0.0f;
+
+__global__ void k_sdf_seed(const float* __restrict__ d_sdf, const float* __restrict__ d_feat, int m, int out, int tangent, float* __restrict__ dZ,
+                           float* __restrict__ db) {
+    STRIP_PROLOGUE(m, out)
+    for (int p = r0; p < r1; ++p) {
+        const size_t i = (size_t)p * out + c;
+        const float g = c == 0 ? (d_sdf ? d_sdf[p] : 0.0f) : (d_feat ? d_feat[(size_t)p * (out - 1) + c - 1] : 0.0f);
+        dZ[i] = g;
+        colsum += g;
         if (tangent) dZ[(size_t)m * out + i] = c == 0 ? 1.0f : 0.0f;  // d<v, grad sdf>/d(tangent output 0) = 1
     }
+    atomicAdd(&db[c], colsum);
 }
 
 // reverse of k_sdf_act: dX [R, ld_dx] holds dL/d(next input) for the columns [0,out); writes dZ [R, out]
 __global__ void k_sdf_act_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, int tangent, float sc,
-                               float* __restrict__ dZ) {
-    GRID_STRIDE(i, (int64_t)m * out) {
-        const int p = (int)(i / out), c = (int)(i % out);
+                               float* __restrict__ dZ, float* __restrict__ db) {
+    STRIP_PROLOGUE(m, out)
+    for (int p = r0; p < r1; ++p) {
+        const size_t i = (size_t)p * out + c;
         float a, s1, s2;
         softplus100(Z[i], &a, &s1, &s2);
         const float abar = dX[(size_t)p * ld_dx + c] * sc;
+        float zbar = s1 * abar;
         if (tangent) {
             const float adotbar = dX[(size_t)(m + p) * ld_dx + c] * sc;
-            dZ[i] = s1 * abar + s2 * Z[(size_t)m * out + i] * adotbar;
+            zbar += s2 * Z[(size_t)m * out + i] * adotbar;
             dZ[(size_t)m * out + i] = s1 * adotbar;
-        } else {
-            dZ[i] = s1 * abar;
         }
+        dZ[i] = zbar;
+        colsum += zbar;
     }
+    atomicAdd(&db[c], colsum);
 }
 
 constexpr int kSdfChunk = 65536;
@@ -320,17 +329,16 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
         }
         // reverse
         const int out_last = ly[L - 1].out_dim;
-        hipLaunchKernelGGL(k_sdf_seed, grid1((int64_t)m * out_last), dim3(256), 0, st, d_sdf ? d_sdf + p0 : nullptr,
-                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ);
+        hipLaunchKernelGGL(k_sdf_seed, strip_grid(m, out_last), dim3(256), 0, st, d_sdf ? d_sdf + p0 : nullptr,
+                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ, P.db[L - 1]);
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
             TR_TRY(gemm_dw(h, st, out, in, R, P.dZ, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
-            hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
             if (l == 0) break;
             TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
             const int outp = ly[l - 1].out_dim;
-            hipLaunchKernelGGL(k_sdf_act_back, grid1((int64_t)m * outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, tangent,
-                               l == d->skip_layer ? rs2 : 1.0f, P.dZ);
+            hipLaunchKernelGGL(k_sdf_act_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, tangent,
+                               l == d->skip_layer ? rs2 : 1.0f, P.dZ, P.db[l - 1]);
         }
     }
     for (int l = 0; l < L; ++l) {
@@ -404,26 +412,35 @@ __global__ void k_relu_act(float* __restrict__ Z, const float* __restrict__ bias
     }
 }
 
-__global__ void k_relu_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, float sc, float* __restrict__ dZ) {
-    GRID_STRIDE(i, (int64_t)m * out) {
-        const int p = (int)(i / out), c = (int)(i % out);
-        dZ[i] = Z[i] > 0.0f ? dX[(size_t)p * ld_dx + c] * sc : 0.0f;
+__global__ void k_relu_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, float sc, float* __restrict__ dZ,
+                            float* __restrict__ db) {
+    STRIP_PROLOGUE(m, out)
+    for (int p = r0; p < r1; ++p) {
+        const size_t i = (size_t)p * out + c;
+        const float g = Z[i] > 0.0f ? dX[(size_t)p * ld_dx + c] * sc : 0.0f;
+        dZ[i] = g;
+        colsum += g;
     }
+    atomicAdd(&db[c], colsum);
 }
 
 // last layer: z = Z + b; y = os (z + ob); optionally sq * sigmoid(y); dZ = dL/dz
 __global__ void k_render_out_back(const float* __restrict__ Z, const float* __restrict__ bias, const float* __restrict__ d_out, int m, int out, float ob,
-                                  float os, int squeeze, float sq, float* __restrict__ dZ) {
-    GRID_STRIDE(i, (int64_t)m * out) {
-        const int c = (int)(i % out);
+                                  float os, int squeeze, float sq, float* __restrict__ dZ, float* __restrict__ db) {
+    STRIP_PROLOGUE(m, out)
+    for (int p = r0; p < r1; ++p) {
+        const size_t i = (size_t)p * out + c;
         float g = d_out[i];
         if (squeeze) {
             const float y = os * ((Z[i] + bias[c]) + ob);
-            const float s = 1.0f / (1.0f + expf(-y));
-            g *= sq * s * (1.0f - s);
+            const float sg = 1.0f / (1.0f + expf(-y));
+            g *= sq * sg * (1.0f - sg);
         }
-        dZ[i] = g * os;
+        g *= os;
+        dZ[i] = g;
+        colsum += g;
     }
+    atomicAdd(&db[c], colsum);
 }
 
 constexpr int kRenderChunk = 131072;
@@ -502,13 +519,12 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
                 hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.X[0], I.D0, m, I.D0, rs2, P.X[l + 1], in_next, out);
         }
         const int out_last = ly[L - 1].out_dim;
-        hipLaunchKernelGGL(k_render_out_back, grid1((int64_t)m * out_last), dim3(256), 0, st, P.Z[L - 1], ly[L - 1].bias, d_out + (size_t)p0 * out_last, m,
-                           out_last, d->output_bias, d->output_scale, d->squeeze_out, d->squeeze_out_scale, P.dZ);
+        hipLaunchKernelGGL(k_render_out_back, strip_grid(m, out_last), dim3(256), 0, st, P.Z[L - 1], ly[L - 1].bias, d_out + (size_t)p0 * out_last, m,
+                           out_last, d->output_bias, d->output_scale, d->squeeze_out, d->squeeze_out_scale, P.dZ, P.db[L - 1]);
         TR_HIP(hipMemsetAsync(P.dIN0, 0, sizeof(float) * (size_t)m * I.D0, st));
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
             TR_TRY(gemm_dw(h, st, out, in, m, P.dZ, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
-            hipLaunchKernelGGL(k_colsum, dim3((out + 63) / 64, (m + 255) / 256), dim3(64), 0, st, P.dZ, m, out, out, P.db[l]);
             TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
             if (l == 0) {
                 hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, 0, m, I.D0, 1.0f, P.dIN0, I.D0);
@@ -517,7 +533,7 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
             const int outp = ly[l - 1].out_dim;
             const bool is_skip = (l == d->skip_layer);
             if (is_skip) hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, outp, m, I.D0, rs2, P.dIN0, I.D0);
-            hipLaunchKernelGGL(k_relu_back, grid1((int64_t)m * outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ);
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ, P.db[l - 1]);
         }
         hipLaunchKernelGGL(k_render_in_back, dim3((m + 255) / 256), dim3(256), 0, st, I, cp, cv, m, P.dIN0, d_pts ? d_pts + 3 * p0 : nullptr,
                            (d_view && I.nv) ? d_view + 3 * p0 : nullptr, d_nrm ? d_nrm + 3 * p0 : nullptr);
