@@ -676,7 +676,7 @@ def render_fn_ggx(scene: Scene, interior_mask: Tensor, ray_o: Tensor, ray_d: Ten
     if interior_mask.any():
         n = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
         prm = get_materials(scene.nets, points, n, feats)
-        res = ggx_colocated(torch.tensor(scene.light, dtype=torch.float32),
+        res = ggx_colocated(scene.light if torch.is_tensor(scene.light) else torch.tensor(scene.light, dtype=torch.float32),
                             (points - ray_o).norm(dim=-1, keepdim=True), n, -ray_d, prm,
                             scene.mts_trans, scene.mts_diff_trans)
         out["color"][interior_mask] = res["rgb"]

@@ -147,3 +147,32 @@ def test_extract_fields_lattice():
     assert np.abs(u - ref).max() <= 2e-5
     u2 = extract_fields(lo, hi, res, lambda p: -sdf.sdf(p))
     assert np.array_equal(u, u2)
+
+
+def test_neus_full_size_batch_properties():
+    """BASELINE config C2 at full size (4096 rays x (64 + 4 x 16) samples + 32 outside), where the oracle is too slow:
+    size-independent properties.  Rays are independent, so rendering the batch in two halves must give the identical
+    result; weights are a sub-probability distribution along each ray; the inside-sphere mask is 0/1.  (No range check on the
+    colour: this fork composites the NeRF field's RAW rgb for the outside samples, renderer.py:173-179, so it can be negative.)"""
+    r = _renderer(_stage1())
+    gen = torch.Generator().manual_seed(9)
+    n = 4096
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen) * torch.tensor([0.3, 0.3, 0.0]) + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    o = torch.tensor([[0.05, -0.02, -2.5]]).expand(n, 3).contiguous()
+    mid = -(o * d).sum(-1, keepdim=True)
+    args = [v.cuda() for v in (o, d, mid - 1.0, mid + 1.0)]
+    full = r.render(*args, perturb_overwrite=0, cos_anneal_ratio=1.0)
+    h1 = r.render(*[a[:1500] for a in args], perturb_overwrite=0, cos_anneal_ratio=1.0)
+    h2 = r.render(*[a[1500:] for a in args], perturb_overwrite=0, cos_anneal_ratio=1.0)
+    for k in ("color_fine", "weights", "cdf_fine", "weight_sum", "weight_max", "gradients", "inside_sphere"):
+        assert torch.equal(full[k], torch.cat([h1[k], h2[k]], dim=0)), k
+    w = full["weights"]
+    assert w.shape == (n, 160) and bool((w >= 0).all()) and float(full["weight_sum"].max()) <= 1.0 + 1e-4
+    assert float((w.sum(dim=-1, keepdim=True) - full["weight_sum"]).abs().max()) <= 1e-5
+    assert float((w.max(dim=-1, keepdim=True)[0] - full["weight_max"]).abs().max()) == 0.0
+    ins = full["inside_sphere"]
+    assert bool(((ins == 0) | (ins == 1)).all())
+    c = full["color_fine"]
+    assert bool(torch.isfinite(c).all())
+    ge = float(full["gradient_error"])
+    assert 0.0 <= ge < 1.0  # geometric init: |grad sdf| is close to 1 inside the relaxed sphere
