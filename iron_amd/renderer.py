@@ -67,6 +67,27 @@ class NeuSRenderer:
         self.n_outside = n_outside
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
+        self._consts = {}   # per device: the two constant sample rows
+        self._inv_s = None  # (variance version, value): 1/s is a parameter, read back once per update, not per batch
+
+    def _constants(self, dev):
+        c = self._consts.get(dev)
+        if c is None:
+            lin = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
+            rev = None
+            if self.n_outside > 0:
+                rev = torch.flip(torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev), dims=[-1]).contiguous()
+            c = self._consts[dev] = (lin, rev)
+        return c
+
+    def _inverse_s(self, dev) -> float:
+        """deviation_network(zeros[1,3])[:, :1].clip(1e-6, 1e6) (renderer.py:283) as a host scalar, cached per parameter version."""
+        var = getattr(self.deviation_network, "variance", None)
+        key = None if var is None else (var.data_ptr(), var._version)
+        if key is None or self._inv_s is None or self._inv_s[0] != key:
+            val = float(self.deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6))
+            self._inv_s = (key, val)
+        return self._inv_s[1]
 
     # ---- per-ray kernels -----------------------------------------------------------------------------------------
     @staticmethod
@@ -141,7 +162,7 @@ class NeuSRenderer:
         sample_dist = 2.0 / self.n_samples
         with torch.cuda.device(dev):
             st = _lib.stream_ptr(dev)
-            lin = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
+            lin, rev = self._constants(dev)
             z_vals = torch.empty((batch, self.n_samples), dtype=torch.float32, device=dev)
             _lib.check(lib.iron_neus_linspace(near.data_ptr(), far.data_ptr(), lin.data_ptr(), batch, self.n_samples, z_vals.data_ptr(), st))
             n_samples = self.n_samples
@@ -156,7 +177,6 @@ class NeuSRenderer:
             keep = []
             if self.n_outside > 0:
                 # far / flip(linspace(1e-3, 1 - 1/(n_outside+1))) + 1/n_samples: one ascending row per ray (:361-381)
-                rev = torch.flip(torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev), dims=[-1]).contiguous()
                 z_out = torch.empty((batch, self.n_outside), dtype=torch.float32, device=dev)
                 _lib.check(lib.iron_neus_outside_z(far.data_ptr(), rev.data_ptr(), batch, self.n_outside, 1.0 / self.n_samples,
                                                    z_out.data_ptr(), st))
@@ -170,7 +190,7 @@ class NeuSRenderer:
             dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, False)
             sdf, feat, grad = self.sdf_network.get_all(pts, is_training=False)
             color = self.color_network(pts, grad, dirs, feat).contiguous()
-            inv_s = float(self.deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6))
+            inv_s = self._inverse_s(dev)
             n_tot = a.mo if self.n_outside > 0 else n_samples
             out_color = torch.empty((batch, 3), dtype=torch.float32, device=dev)
             weights = torch.empty((batch, n_tot), dtype=torch.float32, device=dev)
