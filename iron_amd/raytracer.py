@@ -8,9 +8,9 @@ What differs is only HOW: one persistent kernel pipeline per call instead of a P
 masked torch ops (no host sync inside the tracer), and a fused shading kernel when the render_fn
 is the GGX one from iron_amd.rendering_func.
 
-Built: the forward path (is_training=False) including hole filling and silhouette edge sampling
-(locate_edge_points :421-506, render_edge_pixels :665-729).
-Not built yet: the backward pass.
+Built: the forward path including hole filling and silhouette edge sampling (locate_edge_points :421-506,
+render_edge_pixels :665-729), and is_training=True (reparam_points :17-24, shading and edge blending
+attached to the parameters through the differentiable HIP operators of iron_amd.autograd).
 There is no CPU path: tensors must be CUDA (ROCm) fp32.
 """
 from __future__ import annotations
