@@ -87,6 +87,33 @@ int iron_ggx_colocated_backward(float light, const float* distance, const float*
                                 const float* d_specular_rgb, const float* d_rgb, float* d_light, float* d_distance, float* d_normal,
                                 float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo, float* d_roughness, void* stream);
 
+/* Backward of CompositeRenderer.forward (models/renderer_ggx.py:781-858), point-light branch (p->env_light must be NULL:
+ * IRON_ERR_UNSUPPORTED otherwise).  Upstream: d_rgb (the reference returns the SAME tensor as "rgb" and "diffuse_rgb"; pass
+ * the sum of both keys' gradients), d_specular_rgb, d_metallic_rgb, d_dielectric_rgb, each [n,3] or NULL.  Outputs, each
+ * nullable: d_light [1]; d_distance, the four scalar maps [n]; d_normal, d_viewdir, the two albedos [n,3].  Clamped inputs
+ * carry gradient on the closed clamp interval, the diffuse tables none. */
+typedef struct iron_composite_grads_in {
+    const float* d_rgb;
+    const float* d_specular_rgb;
+    const float* d_metallic_rgb;
+    const float* d_dielectric_rgb;
+} iron_composite_grads_in;
+typedef struct iron_composite_grads_out {
+    float* d_light;
+    float* d_distance;
+    float* d_normal;
+    float* d_viewdir;
+    float* d_diffuse_albedo;
+    float* d_specular_albedo;
+    float* d_specular_roughness;
+    float* d_metallic_eta;
+    float* d_metallic_k;
+    float* d_dielectric_eta;
+} iron_composite_grads_out;
+int iron_composite_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
+                                      const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
+                                      const iron_composite_grads_in* upstream, const iron_composite_grads_out* out, void* stream);
+
 /* Diagnostics: last hipError_t / rocblas_status seen by this library on the calling thread. */
 int iron_train_last_hip_error(void);
 int iron_train_last_blas_status(void);

@@ -141,6 +141,15 @@ class iron_render_train_desc(C.Structure):
                 ("layers", C.POINTER(iron_train_layer))]
 
 
+class iron_composite_grads_in(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("d_rgb", "d_specular_rgb", "d_metallic_rgb", "d_dielectric_rgb")]
+
+
+class iron_composite_grads_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("d_light", "d_distance", "d_normal", "d_viewdir", "d_diffuse_albedo", "d_specular_albedo",
+                                          "d_specular_roughness", "d_metallic_eta", "d_metallic_k", "d_dielectric_eta")]
+
+
 TRAIN_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libiron_train.so")
 TRAIN_SYMBOLS = {
     "iron_sdf_backward_workspace_bytes": (_SZ, [C.POINTER(iron_sdf_train_desc), _I64]),
@@ -148,6 +157,8 @@ TRAIN_SYMBOLS = {
     "iron_render_backward_workspace_bytes": (_SZ, [C.POINTER(iron_render_train_desc), _I64]),
     "iron_render_backward": (C.c_int, [C.POINTER(iron_render_train_desc), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "iron_ggx_colocated_backward": (C.c_int, [_F] + [_P] * 8 + [_I64] + [_P] * 10 + [_P]),
+    "iron_composite_colocated_backward": (C.c_int, [_F, _P, _P, _P, C.POINTER(iron_composite_params), _P, _P, _I64,
+                                                    C.POINTER(iron_composite_grads_in), C.POINTER(iron_composite_grads_out), _P]),
     "iron_train_last_hip_error": (C.c_int, []),
     "iron_train_last_blas_status": (C.c_int, []),
 }

@@ -225,6 +225,75 @@ class GGXColocatedFn(torch.autograd.Function):
                 d_vd.reshape(s_vd), d_kd.reshape(s_kd), d_ks.reshape(s_ks), d_rough.reshape(s_rough))
 
 
+class CompositeFn(torch.autograd.Function):
+    """(rgb, specular_rgb, metallic_rgb, dielectric_rgb) = CompositeRenderer(light, distance, normal, viewdir, kd, ks, roughness,
+    metallic_eta, metallic_k, dielectric_eta), point-light branch (models/renderer_ggx.py:781-858).  "diffuse_rgb" is the same
+    tensor as "rgb" in the reference, so the caller maps both keys to the first output."""
+
+    NAMES = ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta", "metallic_k", "dielectric_eta")
+
+    @staticmethod
+    def forward(ctx, renderer, light, distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta):
+        ctx.set_materialize_grads(False)
+        ctx.renderer = renderer
+        ctx.light_shape = light.shape if torch.is_tensor(light) else None
+        ctx.light_value = float(light)
+        params = dict(zip(CompositeFn.NAMES, (kd, ks, rough, m_eta, m_k, d_eta)))
+        params["metallic"] = params["dielectric"] = rough  # read and ignored by the reference (:829-831)
+        with torch.no_grad():
+            out = renderer._forward_values(ctx.light_value, distance, normal, viewdir, params, False)
+        ctx.shapes = tuple(t.shape for t in (distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta))
+        ctx.save_for_backward(*(t.detach() for t in (distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta)))
+        return out["rgb"], out["specular_rgb"], out["metallic_rgb"], out["dielectric_rgb"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_spec, g_met, g_die):
+        dist, nrm, vd, kd, ks, rough, m_eta, m_k, d_eta = ctx.saved_tensors
+        nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
+        n = nrm.shape[0]
+        dev = nrm.device
+        sh = list(ctx.shapes[1][:-1])
+
+        def vec(t, name):
+            t = _lib.require_cuda_f32(t, name)
+            return (t.expand(sh + [3]) if t.shape[-1] != 3 else t).reshape(-1, 3).contiguous()
+
+        def sca(t, name):
+            return _lib.require_cuda_f32(t, name).reshape(-1)
+
+        dist, vd = sca(dist, "distance"), vec(vd, "viewdir")
+        kd_f, ks_f = vec(kd, "diffuse_albedo"), vec(ks, "specular_albedo")
+        maps = [sca(t, k) for t, k in zip((rough, m_eta, m_k, d_eta), CompositeFn.NAMES[2:])]
+        t1, t2 = ctx.renderer._tables_on(dev)
+        ups = [_opt(g, (-1, 3)) for g in (g_rgb, g_spec, g_met, g_die)]
+        lib = _lib.load_train()
+        with torch.cuda.device(dev):
+            p = _lib.iron_composite_params()
+            p.diffuse_albedo, p.specular_albedo, p.specular_roughness = kd_f.data_ptr(), ks_f.data_ptr(), maps[0].data_ptr()
+            p.metallic_eta, p.metallic_k, p.dielectric_eta, p.env_light = maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), None
+            gi = _lib.iron_composite_grads_in()
+            gi.d_rgb, gi.d_specular_rgb, gi.d_metallic_rgb, gi.d_dielectric_rgb = (_lib.ptr(u) for u in ups)
+            d_light = torch.zeros(1, dtype=torch.float32, device=dev)
+            d_dist = torch.empty_like(dist)
+            d_nrm, d_vd, d_kd, d_ks = (torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(4))
+            d_maps = [torch.empty_like(m) for m in maps]
+            go = _lib.iron_composite_grads_out()
+            go.d_light, go.d_distance, go.d_normal, go.d_viewdir = d_light.data_ptr(), d_dist.data_ptr(), d_nrm.data_ptr(), d_vd.data_ptr()
+            go.d_diffuse_albedo, go.d_specular_albedo = d_kd.data_ptr(), d_ks.data_ptr()
+            go.d_specular_roughness, go.d_metallic_eta, go.d_metallic_k, go.d_dielectric_eta = (m.data_ptr() for m in d_maps)
+            _lib.check_train(lib.iron_composite_colocated_backward(ctx.light_value, dist.data_ptr(), nrm.data_ptr(), vd.data_ptr(), C.byref(p),
+                                                                   t1.data_ptr(), t2.data_ptr(), n, C.byref(gi), C.byref(go),
+                                                                   _lib.stream_ptr(dev)))
+        s_dist, s_nrm, s_vd, s_kd, s_ks = ctx.shapes[:5]
+
+        def unvec(g, shape):
+            g = g.reshape(sh + [3])
+            return (g.sum(dim=-1, keepdim=True) if shape[-1] == 1 else g).reshape(shape)
+
+        return (None, d_light.reshape(ctx.light_shape) if ctx.light_shape is not None else None, d_dist.reshape(s_dist), d_nrm.reshape(s_nrm),
+                d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(m.reshape(s) for m, s in zip(d_maps, ctx.shapes[5:]))
+
+
 def any_requires_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
 

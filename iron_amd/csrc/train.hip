@@ -637,9 +637,161 @@ __global__ void k_ggx_back(float light, const float* __restrict__ dist, const fl
     }
 }
 
+// ---- CompositeRenderer (models/renderer_ggx.py:781-858, point-light branch): duals in (cos, roughness, distance, metallic eta,
+// metallic k, dielectric eta); linear in the two albedos and the light.  Same expressions as csrc/ggx_core.h:composite_point.
+template <int N>
+struct Dual {
+    float v, d[N];
+};
+template <int N> __device__ __forceinline__ Dual<N> dc(float c) { Dual<N> r; r.v = c; for (int i = 0; i < N; ++i) r.d[i] = 0.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dvar(float x, int k) { Dual<N> r = dc<N>(x); r.d[k] = 1.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(Dual<N> a, Dual<N> b) {
+    Dual<N> r; r.v = a.v / b.v; const float ib = 1.0f / b.v;
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dsqrt(Dual<N> a) {
+    Dual<N> r; r.v = sqrtf(a.v); const float k = 0.5f / r.v;
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * k;
+    return r;
+}
+
+struct CompBackArgs {
+    const float *dist, *nrm, *view, *kd, *ks, *rough, *m_eta, *m_k, *d_eta, *tab_trans, *tab_diff;
+    const float *g_rgb, *g_spec, *g_met, *g_die;
+    float *d_light, *d_dist, *d_nrm, *d_view, *d_kd, *d_ks, *d_rough, *d_m_eta, *d_m_k, *d_d_eta;
+    float light;
+    int n;
+};
+
+__global__ void k_composite_back(CompBackArgs a) {
+    typedef Dual<6> D6;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float light_acc = 0.0f;
+    if (p < a.n) {
+        const float* nn = a.nrm + 3 * (size_t)p;
+        const float* vv = a.view + 3 * (size_t)p;
+        const float raw_dot = (vv[0] * nn[0] + vv[1] * nn[1]) + vv[2] * nn[2];
+        const float cdot = fminf(fmaxf(raw_dot, 0.00001f), 0.99999f);
+        const bool dot_live = raw_dot >= 0.00001f && raw_dot <= 0.99999f;
+        const float r_in = a.rough[p], me_in = a.m_eta[p], mk_in = a.m_k[p], de_in = a.d_eta[p];
+        const float rough0 = fmaxf(r_in, 0.00001f);
+        const float de0 = fminf(fmaxf(de_in, 1.000001f), 1.999999f);
+        const float me0 = fminf(fmaxf(me_in, 0.099999f), 4.999999f);
+        const float mk0 = fminf(fmaxf(mk_in, 0.099999f), 9.999999f);
+        const bool live[6] = {dot_live, r_in >= 0.00001f, true, me_in >= 0.099999f && me_in <= 4.999999f,
+                              mk_in >= 0.099999f && mk_in <= 9.999999f, de_in >= 1.000001f && de_in <= 1.999999f};
+        // piecewise-constant diffuse tables (alpha := max(rough, 1e-4) as CompositeRenderer.diffuse_reflection_ggx does)
+        const float alpha_t = fmaxf(rough0, 0.0001f);
+        const long long tx = (long long)floorf(powf(cdot, 0.25f) * 100.0f);
+        const long long ty = (long long)floorf(powf(alpha_t / 4.0f, 0.25f) * 50.0f);
+        long long ti = ty * 100 + tx;
+        ti = ti < 0 ? 0 : (ti > 4999 ? 4999 : ti);
+        const float T12 = fminf(fmaxf(a.tab_trans[ti], 0.0f), 1.0f);
+        const long long ai = ty < 0 ? 0 : (ty > 49 ? 49 : ty);
+        const float Fdr = fminf(fmaxf(1.0f - a.tab_diff[ai], 0.0f), 1.0f);
+        const float fd = 1.0f - Fdr + 1e-10f;
+        const float pi_f = 3.14159274101257324219f;
+        const float inv_eta2 = (float)(1.0 / (1.48958738 * 1.48958738));
+        const float eta2 = (float)(1.48958738 * 1.48958738 + 1e-10);
+        const float pi_eta2 = (float)(3.141592653589793 * 1.48958738 * 1.48958738);
+
+        const D6 c = dvar<6>(cdot, 0), rg = dvar<6>(rough0, 1), ds = dvar<6>(a.dist[p], 2), me = dvar<6>(me0, 3), mk = dvar<6>(mk0, 4),
+                 de = dvar<6>(de0, 5);
+        const D6 one = dc<6>(1.0f);
+        const D6 U = one / (ds * ds + dc<6>(1e-10f));
+        const D6 c2 = c * c, s2 = one - c2;
+        // GGX NDF with alpha := eta (the reference's quirk), Smith G1 with the roughness
+        const D6 root = c2 + s2 / dc<6>(eta2);
+        const D6 Dn = one / (dc<6>(pi_eta2) * root * root + dc<6>(1e-10f));
+        const D6 tan_t = dsqrt(s2) / (c + dc<6>(1e-10f));
+        const D6 rt = rg * tan_t;
+        const D6 g1 = dc<6>(2.0f) / (one + dsqrt(rt * rt + one));
+        // conductor Fresnel
+        const D6 s4 = s2 * s2;
+        const D6 temp1 = me * me - mk * mk - s2;
+        const D6 a2pb2 = dsqrt(temp1 * temp1 + dc<6>(4.0f) * mk * mk * me * me);
+        const D6 aa = dsqrt(dc<6>(0.5f) * (a2pb2 + temp1));
+        const D6 term1 = a2pb2 + c2, term2 = dc<6>(2.0f) * aa * c;
+        const D6 rs2 = (term1 - term2) / (term1 + term2);
+        const D6 term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+        const D6 rp2 = rs2 * (term3 - term4) / (term3 + term4);
+        const D6 Fm = dc<6>(0.5f) * (rp2 + rs2);
+        // dielectric Fresnel (cos > 0)
+        const D6 sc = one / de;
+        const D6 cos_t = dsqrt(one - s2 * (sc * sc));
+        const D6 rs = (c - de * cos_t) / (c + de * cos_t);
+        const D6 rp = (de * c - cos_t) / (de * c + cos_t);
+        const D6 Fd = dc<6>(0.5f) * (rs * rs + rp * rp);
+
+        const D6 M = Fm * U;                                            // metallic   per unit light and specular albedo
+        const D6 Dl = Fd * Dn * (g1 * g1) / (dc<6>(4.0f) * c) * U;      // dielectric per unit light and specular albedo
+        const D6 Df = U * c * dc<6>(T12 * T12 * inv_eta2 / (fd * pi_f)); // diffuse    per unit light and diffuse albedo
+        float Am = 0.f, Ad = 0.f, Af = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t q = 3 * (size_t)p + k;
+            const float g_r = a.g_rgb ? a.g_rgb[q] : 0.f, g_s = a.g_spec ? a.g_spec[q] : 0.f;
+            const float gm = (a.g_met ? a.g_met[q] : 0.f) + g_s + g_r;
+            const float gd = (a.g_die ? a.g_die[q] : 0.f) + g_s + g_r;
+            const float ks_in = a.ks[q], kd_in = a.kd[q];
+            const float ks = fmaxf(ks_in, 0.00001f), kd = fmaxf(kd_in, 0.00001f);
+            if (a.d_ks) a.d_ks[q] = ks_in >= 0.00001f ? a.light * (gm * M.v + gd * Dl.v) : 0.f;
+            if (a.d_kd) a.d_kd[q] = kd_in >= 0.00001f ? a.light * (g_r * Df.v) : 0.f;
+            Am += gm * ks; Ad += gd * ks; Af += g_r * kd;
+        }
+        light_acc = (Am * M.v + Ad * Dl.v) + Af * Df.v;
+        float dv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dv[k] = live[k] ? a.light * ((Am * M.d[k] + Ad * Dl.d[k]) + Af * Df.d[k]) : 0.f;
+        if (a.d_rough) a.d_rough[p] = dv[1];
+        if (a.d_dist) a.d_dist[p] = dv[2];
+        if (a.d_m_eta) a.d_m_eta[p] = dv[3];
+        if (a.d_m_k) a.d_m_k[p] = dv[4];
+        if (a.d_d_eta) a.d_d_eta[p] = dv[5];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.d_nrm) a.d_nrm[3 * (size_t)p + k] = dv[0] * vv[k];
+            if (a.d_view) a.d_view[3 * (size_t)p + k] = dv[0] * nn[k];
+        }
+    }
+    if (a.d_light) {
+        for (int o = 32; o > 0; o >>= 1) light_acc += __shfl_xor(light_acc, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.d_light, light_acc);
+    }
+}
+
 }  // namespace iron_train
 
 using namespace iron_train;
+
+extern "C" int iron_composite_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
+                                                 const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
+                                                 const iron_composite_grads_in* g, const iron_composite_grads_out* o, void* stream) {
+    if (n < 0 || !p || !g || !o) return IRON_ERR_BAD_ARG;
+    if (p->env_light) return IRON_ERR_UNSUPPORTED;  // the env-light branch has no backward here
+    hipStream_t st = (hipStream_t)stream;
+    if (o->d_light) TR_HIP(hipMemsetAsync(o->d_light, 0, sizeof(float), st));
+    if (n == 0) return IRON_OK;
+    if (!distance || !normal || !viewdir || !p->diffuse_albedo || !p->specular_albedo || !p->specular_roughness || !p->metallic_eta ||
+        !p->metallic_k || !p->dielectric_eta || !tab_trans || !tab_diff)
+        return IRON_ERR_BAD_ARG;
+    CompBackArgs a;
+    a.dist = distance; a.nrm = normal; a.view = viewdir; a.kd = p->diffuse_albedo; a.ks = p->specular_albedo; a.rough = p->specular_roughness;
+    a.m_eta = p->metallic_eta; a.m_k = p->metallic_k; a.d_eta = p->dielectric_eta; a.tab_trans = tab_trans; a.tab_diff = tab_diff;
+    a.g_rgb = g->d_rgb; a.g_spec = g->d_specular_rgb; a.g_met = g->d_metallic_rgb; a.g_die = g->d_dielectric_rgb;
+    a.d_light = o->d_light; a.d_dist = o->d_distance; a.d_nrm = o->d_normal; a.d_view = o->d_viewdir; a.d_kd = o->d_diffuse_albedo;
+    a.d_ks = o->d_specular_albedo; a.d_rough = o->d_specular_roughness; a.d_m_eta = o->d_metallic_eta; a.d_m_k = o->d_metallic_k;
+    a.d_d_eta = o->d_dielectric_eta;
+    a.light = light; a.n = (int)n;
+    hipLaunchKernelGGL(k_composite_back, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
 
 extern "C" int iron_train_last_hip_error(void) { return g_hip_error; }
 extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }

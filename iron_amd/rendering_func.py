@@ -76,8 +76,8 @@ class CompRenderFn:
         if interior_mask.any():
             normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
             params = get_materials_comp(color_network_dict, points, normals, features)
-            light = color_network_dict["point_light_network"]().detach()
-            res = self.renderer(float(light), (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d, params=params)
+            light = color_network_dict["point_light_network"]()  # a Parameter: trainable under is_training
+            res = self.renderer(light, (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d, params=params)
             out["color"][interior_mask] = res["rgb"]
             out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
             out["specular_color"][interior_mask] = res["specular_rgb"]

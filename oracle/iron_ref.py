@@ -432,7 +432,7 @@ def render_fn_comp(nets, light: float, mts_trans: Tensor, mts_diff_trans: Tensor
     if interior_mask.any():
         n = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
         prm = get_materials_comp(nets, points, n, feats)
-        res = composite_forward(torch.tensor(light, dtype=torch.float32), (points - ray_o).norm(dim=-1, keepdim=True), n,
+        res = composite_forward(light if torch.is_tensor(light) else torch.tensor(light, dtype=torch.float32), (points - ray_o).norm(dim=-1, keepdim=True), n,
                                 -ray_d, prm, mts_trans, mts_diff_trans)
         out["color"][interior_mask] = res["rgb"]
         out["diffuse_color"][interior_mask] = res["diffuse_rgb"]

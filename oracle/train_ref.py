@@ -56,7 +56,10 @@ def render_normal_and_color_train(scene: R.Scene, res: Dict[str, Tensor]) -> Non
     else:
         p = d = o = grad = feat = torch.zeros(0, dtype=torch.float32)
     with torch.enable_grad():
-        r = R.render_fn_ggx(scene, m, o, d, p, grad, feat)
+        if scene.renderer == "comp":  # render_fn_comp, render_surface.py:159-234
+            r = R.render_fn_comp(scene.nets, scene.light, scene.mts_trans, scene.mts_diff_trans, m, o, d, p, grad, feat)
+        else:
+            r = R.render_fn_ggx(scene, m, o, d, p, grad, feat)
     for k, v in r.items():
         v = v.reshape(sh + [-1])
         res[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
@@ -106,17 +109,6 @@ def render_camera_train(scene: R.Scene, cam: R.CameraSpec) -> Dict[str, Tensor]:
     grad (raytracer.py:542 @torch.no_grad), shading with it.  `scene`'s state dicts must be leaf_state()s."""
     with torch.no_grad():
         res = R.raytrace_camera(scene, cam, max_num_rays=50000)
-    sh = list(res["convergent_mask"].shape)
-    m = res["convergent_mask"].reshape(-1)
-    assert bool(m.any()), "the golden crop has hits"
-    p = res["points"].reshape(-1, 3)[m]
-    d = res["ray_d"].reshape(-1, 3)[m]
-    o = res["ray_o"].reshape(-1, 3)[m]
-    sdf, feat, grad = sdf_get_all_train(scene.sdf_sd, scene.sdf_spec, p)
-    p = reparam_points(p, grad.detach(), -d.detach(), sdf)
-    with torch.enable_grad():
-        r = R.render_fn_ggx(scene, m, o, d, p, grad, feat)
-    for k, v in r.items():
-        v = v.reshape(sh + [-1])
-        res[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+    assert bool(res["convergent_mask"].any()), "the golden crop has hits"
+    render_normal_and_color_train(scene, res)
     return res

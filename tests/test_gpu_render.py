@@ -140,7 +140,7 @@ def test_training_mode_renders_the_same_image_attached_to_the_parameters():
 
 
 def test_heads_without_a_backward_refuse_inputs_that_require_grad():
-    """Only the GGX path has a backward (row f-2): the composite / other BRDF heads and the NeRF field must not silently
+    """Operators without a backward (the simple BRDF heads, the composite env-light branch, the NeRF field) must not silently
     return detached results inside a training graph."""
     from iron_amd.fields import NeRF
     from iron_amd.renderer_ggx import CompositeRenderer
@@ -152,10 +152,15 @@ def test_heads_without_a_backward_refuse_inputs_that_require_grad():
         nerf(torch.rand(8, 4, device="cuda"), z)
     kd = torch.rand(8, 3, device="cuda", requires_grad=True)
     one = torch.rand(8, 1, device="cuda")
-    params = {"diffuse_albedo": kd, "specular_albedo": z, "metallic": one, "dielectric": one, "specular_roughness": one * 0.3 + 0.05,
-              "metallic_eta": one + 1, "metallic_k": one + 2, "dielectric_eta": one + 1.2}
+    from iron_amd.renderer_ggx import SmoothDielectricRenderer
+    nv = torch.nn.functional.normalize(z, dim=-1)
     with pytest.raises(NotImplementedError):
-        CompositeRenderer(use_cuda=True)(5.0, one + 1, torch.nn.functional.normalize(z, dim=-1), torch.nn.functional.normalize(z, dim=-1), params=params)
+        SmoothDielectricRenderer(use_cuda=True)(5.0, one + 1, nv, nv, kd, z)
+    params = {"diffuse_albedo": kd, "specular_albedo": z, "metallic": one, "dielectric": one, "specular_roughness": one * 0.3 + 0.05,
+              "metallic_eta": one + 1, "metallic_k": one + 2, "dielectric_eta": one + 1.2, "env_light": one}
+    with pytest.raises(NotImplementedError):  # the composite head has a backward on the point-light branch only
+        CompositeRenderer(use_cuda=True)(5.0, one + 1, nv, nv, params=params, use_env_light=True)
+    assert CompositeRenderer(use_cuda=True)(5.0, one + 1, nv, nv, params=params)["rgb"].requires_grad
 
 
 @pytest.mark.parametrize("seed,sigma,yaw", [(2, 0.008, 20.0), (3, 0.012, 135.0), (4, 0.016, 250.0)])
