@@ -17,7 +17,8 @@
  *
  * Conventions as iron_hip.h: device pointers, fp32 row-major contiguous, caller-owned buffers and workspace, work enqueued
  * on `stream`, IRON_OK or a negative iron_status.  Parameter gradients are WRITTEN (not accumulated) to the d_* pointers
- * of each layer.
+ * of each layer.  Threading: the two GEMM-based entries (iron_sdf_backward, iron_render_backward) share one rocBLAS handle per
+ * device and serialise their host-side enqueue per process; the work itself runs asynchronously on the caller's stream.
  */
 #ifndef IRON_TRAIN_H
 #define IRON_TRAIN_H

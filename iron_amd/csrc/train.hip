@@ -36,6 +36,10 @@ thread_local int g_blas_status = 0;
         if (_r != IRON_OK) return _r; \
     } while (0)
 
+// One rocBLAS handle per device is shared by every caller of this library; a handle must not be driven from two host threads
+// at once, so the two GEMM-based entry points serialise per process (the work itself is asynchronous on the caller's stream).
+static std::mutex g_blas_use;
+
 static rocblas_handle blas_for_current_device() {
     static std::mutex mu;
     static rocblas_handle handles[64] = {};
@@ -301,6 +305,7 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
     SdfPlan P;
     TR_TRY(sdf_plan(d, n, ws, P));
     if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
+    std::lock_guard<std::mutex> blas_lock(g_blas_use);
     rocblas_handle h = blas_for_current_device();
     if (!h) return IRON_ERR_HIP;
     TR_BLAS(rocblas_set_stream(h, st));
@@ -491,6 +496,7 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
     if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
     const RenderIn& I = P.in;
     if (n > 0 && (!pts || !d_out || (I.nf && !feat) || (I.nn && !nrm) || (I.nv && !view))) return IRON_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> blas_lock(g_blas_use);
     rocblas_handle h = blas_for_current_device();
     if (!h) return IRON_ERR_HIP;
     TR_BLAS(rocblas_set_stream(h, st));
