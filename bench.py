@@ -48,7 +48,42 @@ def parse():
                     help="N=1 only: fill_holes=True, handle_edges=True (the reference's validation render, SURVEY row f-1) "
                          "instead of the headline configuration")
     ap.add_argument("--cpu-sample-res", type=int, default=160)
+    ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c1",
+                    help="c1 (default): the BASELINE headline, 800x800 sphere-trace + GGX shade.  c2 / c3 (N=1 only): the other two "
+                         "single-GPU BASELINE configurations, reported in their own units without a roofline object -- "
+                         "c2 = stage-1 NeuS forward, 4096 rays x 128 samples per step; c3 = one stage-2 training step with edge "
+                         "sampling at 512x512")
     return ap.parse_args()
+
+
+def secondary_workload(a):
+    """BASELINE configs C2 / C3 through the same entry point (tools/neus_frames.py, tools/train_step.py do the work)."""
+    if a.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload %s is a single-GPU configuration" % a.workload)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from iron_amd import _lib
+    _lib.load()
+    base = {"n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "roofline": None, "cpu_baseline": None}
+    if a.workload == "c2":
+        import neus_frames
+        r = neus_frames.run(rays=4096 * a.steps, batches=(4096,), repeats=1)[0]
+        base.update({"metric": "krays/s stage-1 NeuS volume render (models/renderer.py), 4096 rays x 128 samples hierarchical",
+                     "value": r["krays_per_s"], "unit": "krays/s", "ms_per_step": round(r["ms"] / a.steps, 3),
+                     "config": {"workload": "C2: seeded networks of confs/womask_iron.conf (8x256 SDF, 8-layer PE-10 colour net, NeRF "
+                                            "background with 32 outside samples), 4096 rays per step, 64 + 4x16 samples, perturb = 0",
+                                "mlp_points_per_ray": r["mlp_points_per_ray"]}})
+    else:
+        import train_step
+        _lib.load_train()
+        r = train_step.run(size=512, steps=a.steps, warmup=max(a.warmup, 1))
+        base.update({"metric": "training steps/s, stage-2 with backward (autograd through the HIP operators + edge-sample silhouette "
+                               "gradient), 512x512", "value": r["steps_per_s"], "unit": "steps/s", "ms_per_step": r["ms_step"],
+                     "config": {"workload": "C3: scene S1, render_camera(handle_edges=True, is_training=True), L1 image loss + eikonal "
+                                            "term on %d points, backward, Adam on all networks" % r["eikonal_points"],
+                                "hits": r["hits"], "edge_pixels": r["edge_pixels"], "ms_forward_render": r["ms_forward_render"],
+                                "ms_loss_backward": r["ms_loss_backward"], "ms_adam": r["ms_adam"]}})
+    print(json.dumps(base))
 
 
 def cpu_baseline(scene: str, res: int):
@@ -81,6 +116,8 @@ def cpu_baseline(scene: str, res: int):
 
 def main():
     a = parse()
+    if a.workload != "c1":
+        return secondary_workload(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -17,6 +17,16 @@ def main():
     ap.add_argument("--rays", type=int, default=40000)
     ap.add_argument("--batches", type=int, nargs="+", default=[512, 4096, 16384])
     a = ap.parse_args()
+    for line in run(a.rays, a.batches):
+        print(json.dumps(line))
+
+
+def run(rays: int = 40000, batches=(4096,), repeats: int = 1):
+    """-> one dict per batch size."""
+    class A:
+        pass
+    a = A()
+    a.rays, a.batches = rays, list(batches)
     from iron_amd.fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
     from iron_amd.renderer import NeuSRenderer
     torch.manual_seed(0)
@@ -33,6 +43,7 @@ def main():
     mid = -(o * d).sum(-1, keepdim=True)
     near, far = mid - 1.0, mid + 1.0
     o, d, near, far = o.cuda(), d.cuda(), near.cuda(), far.cuda()
+    out = []
     for b in a.batches:
         def frame():
             for s in range(0, a.rays, b):
@@ -40,11 +51,13 @@ def main():
         frame()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        frame()
+        for _ in range(repeats):
+            frame()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print(json.dumps({"rays": a.rays, "batch": b, "ms": round(dt * 1e3, 2), "krays_per_s": round(a.rays / dt / 1e3, 1),
-                          "mlp_points_per_ray": 64 + 48 + 128 + 128 + 160}))
+        dt = (time.perf_counter() - t0) / repeats
+        out.append({"rays": a.rays, "batch": b, "ms": round(dt * 1e3, 2), "krays_per_s": round(a.rays / dt / 1e3, 1),
+                    "mlp_points_per_ray": 64 + 48 + 128 + 128 + 160})
+    return out
 
 
 if __name__ == "__main__":

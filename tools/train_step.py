@@ -19,6 +19,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-edges", action="store_true")
     a = ap.parse_args()
+    print(json.dumps(run(a.size, a.steps, a.no_edges)))
+
+
+def run(size: int = 512, steps: int = 5, no_edges: bool = False, warmup: int = 1) -> dict:
+    class A:
+        pass
+    a = A()
+    a.size, a.steps, a.no_edges = size, steps, no_edges
     from iron_amd import scenes
     from iron_amd.raytracer import Camera, RayTracer, render_camera
     from iron_amd.renderer_ggx import GGXColocatedRenderer
@@ -33,7 +41,7 @@ def main():
     target = torch.rand(a.size, a.size, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     tracer = RayTracer()
     times = []
-    for step in range(a.steps + 1):
+    for step in range(a.steps + warmup):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = render_camera(cam, nets["sdf_network"], tracer, nets, fn, fill_holes=False, handle_edges=not a.no_edges, is_training=True)
@@ -51,14 +59,14 @@ def main():
         opt.step()
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        if step > 0:  # step 0 = warm-up (library load, rocBLAS kernels, allocator)
+        if step >= warmup:  # warm-up: library load, rocBLAS kernels, allocator
             times.append((t1 - t0, t2 - t1, t3 - t2))
         hits, edges = int(res["convergent_mask"].sum()), int(res["edge_mask"].sum()) if "edge_mask" in res else 0
     f, b, o = (sum(x[i] for x in times) / len(times) * 1e3 for i in range(3))
-    print(json.dumps({"config": "C3 stage-2 training step %dx%d S1%s" % (a.size, a.size, "" if not a.no_edges else " (no edge sampling)"),
-                      "hits": hits, "edge_pixels": edges, "eikonal_points": a.size * a.size // 2, "ms_forward_render": round(f, 2),
-                      "ms_loss_backward": round(b, 2), "ms_adam": round(o, 2), "ms_step": round(f + b + o, 2),
-                      "steps_per_s": round(1e3 / (f + b + o), 2), "loss": float(loss)}))
+    return {"config": "C3 stage-2 training step %dx%d S1%s" % (a.size, a.size, "" if not a.no_edges else " (no edge sampling)"),
+            "hits": hits, "edge_pixels": edges, "eikonal_points": a.size * a.size // 2, "ms_forward_render": round(f, 2),
+            "ms_loss_backward": round(b, 2), "ms_adam": round(o, 2), "ms_step": round(f + b + o, 2),
+            "steps_per_s": round(1e3 / (f + b + o), 2), "loss": float(loss.detach())}
 
 
 if __name__ == "__main__":
