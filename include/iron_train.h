@@ -115,6 +115,27 @@ int iron_composite_colocated_backward(float light, const float* distance, const 
                                       const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
                                       const iron_composite_grads_in* upstream, const iron_composite_grads_out* out, void* stream);
 
+/* Backward of iron_neus_composite (the compositing of NeuSRenderer.render_core, models/renderer.py:279-344, with the
+ * background blend of :174-178).  `fwd` = the forward call's argument block (its output pointers are ignored).  Upstream,
+ * each nullable: d_color [n,3], d_weight_sum [n], d_weights [n, mo or m], d_gradient_error [1] (device; needs relax_count =
+ * the forward's gradient_error_acc + 1, i.e. the sum of the relax mask).  Outputs, each nullable: d_sdf [n*m], d_grad
+ * [n*m,3] (through the annealed cosine and the eikonal statistic), d_sample_color [n*m,3], d_inv_s [1], d_bg_density
+ * [n*mo], d_bg_color [n*mo,3]. */
+typedef struct iron_neus_composite_grads {
+    const float* d_color;
+    const float* d_weight_sum;
+    const float* d_weights;
+    const float* d_gradient_error;
+    const float* relax_count;
+    float* d_sdf;
+    float* d_grad;
+    float* d_sample_color;
+    float* d_inv_s;
+    float* d_bg_density;
+    float* d_bg_color;
+} iron_neus_composite_grads;
+int iron_neus_composite_backward(const iron_neus_composite_args* fwd, const iron_neus_composite_grads* grads, void* stream);
+
 /* Diagnostics: last hipError_t / rocblas_status seen by this library on the calling thread. */
 int iron_train_last_hip_error(void);
 int iron_train_last_blas_status(void);

@@ -294,6 +294,87 @@ class CompositeFn(torch.autograd.Function):
                 d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(m.reshape(s) for m, s in zip(d_maps, ctx.shapes[5:]))
 
 
+class NeusCompositeFn(torch.autograd.Function):
+    """The compositing of NeuSRenderer.render_core (models/renderer.py:279-344, background blend :174-178) from the network
+    outputs at the section mid points: (sdf [n*m,1], grad [n*m,3], colour [n*m,3], 1/s, background density / colour) ->
+    (color [n,3], weights, weight_sum, gradient_error, cdf, inside_sphere, weight_max).  The last three carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, color, inv_s, bg_density, bg_color, dists, pts, dirs, bg_dists, background_rgb, cos_anneal_ratio):
+        ctx.set_materialize_grads(False)
+        n, m = dists.shape
+        dev = dists.device
+        f32 = lambda t, name: _lib.require_cuda_f32(t.detach(), name)
+        sdf_c, grad_c, color_c = f32(sdf, "sdf").reshape(-1), f32(grad, "gradients").reshape(-1, 3), f32(color, "sampled_color").reshape(-1, 3)
+        dists_c, pts_c, dirs_c = f32(dists, "dists"), f32(pts, "pts").reshape(-1, 3), f32(dirs, "dirs").reshape(-1, 3)
+        bg = bg_density is not None
+        mo = bg_dists.shape[1] if bg else m
+        keep = [sdf_c, grad_c, color_c, dists_c, pts_c, dirs_c]
+        a = _lib.iron_neus_composite_args()
+        a.dists, a.pts, a.dirs, a.sdf, a.grad, a.color = (t.data_ptr() for t in (dists_c, pts_c, dirs_c, sdf_c, grad_c, color_c))
+        if bg:
+            bgd, bgc, bgdist = f32(bg_density, "density").reshape(-1), f32(bg_color, "background colour").reshape(-1, 3), f32(bg_dists, "bg_dists")
+            keep += [bgd, bgc, bgdist]
+            a.bg_dists, a.bg_density, a.bg_color = bgdist.data_ptr(), bgd.data_ptr(), bgc.data_ptr()
+        bgrgb = f32(background_rgb, "background_rgb").reshape(3) if background_rgb is not None else None
+        a.background_rgb = _lib.ptr(bgrgb)
+        a.n, a.m, a.mo = n, m, mo
+        inv_s_value = float(inv_s)
+        a.inv_s, a.cos_anneal_ratio = inv_s_value, float(cos_anneal_ratio)
+        out_color = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        weights = torch.empty((n, mo), dtype=torch.float32, device=dev)
+        cdf = torch.empty((n, m), dtype=torch.float32, device=dev)
+        inside = torch.empty((n, m), dtype=torch.float32, device=dev)
+        wsum = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        wmax = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        gacc = torch.zeros(2, dtype=torch.float32, device=dev)
+        a.out_color, a.weights, a.cdf, a.inside_sphere = out_color.data_ptr(), weights.data_ptr(), cdf.data_ptr(), inside.data_ptr()
+        a.weight_sum, a.weight_max, a.gradient_error_acc = wsum.data_ptr(), wmax.data_ptr(), gacc.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().iron_neus_composite(C.byref(a), _lib.stream_ptr(dev)))
+        gerr = gacc[0] / (gacc[1] + 1e-5)
+        ctx.meta = (n, m, mo, bg, inv_s_value, float(cos_anneal_ratio), torch.is_tensor(inv_s), tuple(sdf.shape), tuple(grad.shape), tuple(color.shape),
+                    None if not bg else tuple(bg_density.shape), None if not bg else tuple(bg_color.shape))
+        ctx.save_for_backward(gacc, *(keep + ([bgrgb] if bgrgb is not None else [])))
+        ctx.has_bgrgb = bgrgb is not None
+        ctx.mark_non_differentiable(cdf, inside, wmax)
+        return out_color, weights, wsum, gerr, cdf, inside, wmax
+
+    @staticmethod
+    def backward(ctx, d_color, d_weights, d_wsum, d_gerr, _dc, _di, _dm):
+        n, m, mo, bg, inv_s_value, ca, inv_s_is_tensor, s_sdf, s_grad, s_color, s_bgd, s_bgc = ctx.meta
+        saved = list(ctx.saved_tensors)
+        gacc, sdf_c, grad_c, color_c, dists_c, pts_c, dirs_c = saved[:7]
+        k = 7
+        bgd = bgc = bgdist = None
+        if bg:
+            bgd, bgc, bgdist = saved[k:k + 3]
+            k += 3
+        bgrgb = saved[k] if ctx.has_bgrgb else None
+        dev = dists_c.device
+        a = _lib.iron_neus_composite_args()
+        a.dists, a.pts, a.dirs, a.sdf, a.grad, a.color = (t.data_ptr() for t in (dists_c, pts_c, dirs_c, sdf_c, grad_c, color_c))
+        if bg:
+            a.bg_dists, a.bg_density, a.bg_color = bgdist.data_ptr(), bgd.data_ptr(), bgc.data_ptr()
+        a.background_rgb = _lib.ptr(bgrgb)
+        a.n, a.m, a.mo, a.inv_s, a.cos_anneal_ratio = n, m, mo, inv_s_value, ca
+        g = _lib.iron_neus_composite_grads()
+        ups = [_opt(d_color, (n, 3)), _opt(d_wsum, (n,)), _opt(d_weights, (n, mo)), _opt(d_gerr, (1,))]
+        g.d_color, g.d_weight_sum, g.d_weights, g.d_gradient_error = (_lib.ptr(u) for u in ups)
+        relax = gacc[1:2].contiguous()
+        g.relax_count = relax.data_ptr()
+        d_sdf, d_grad, d_col = torch.empty_like(sdf_c), torch.empty_like(grad_c), torch.empty_like(color_c)
+        d_inv = torch.zeros(1, dtype=torch.float32, device=dev)
+        d_bgd = torch.empty_like(bgd) if bg else None
+        d_bgc = torch.empty_like(bgc) if bg else None
+        g.d_sdf, g.d_grad, g.d_sample_color, g.d_inv_s = d_sdf.data_ptr(), d_grad.data_ptr(), d_col.data_ptr(), d_inv.data_ptr()
+        g.d_bg_density, g.d_bg_color = _lib.ptr(d_bgd), _lib.ptr(d_bgc)
+        with torch.cuda.device(dev):
+            _lib.check_train(_lib.load_train().iron_neus_composite_backward(C.byref(a), C.byref(g), _lib.stream_ptr(dev)))
+        return (d_sdf.reshape(s_sdf), d_grad.reshape(s_grad), d_col.reshape(s_color), d_inv.reshape(()) if inv_s_is_tensor else None,
+                d_bgd.reshape(s_bgd) if bg else None, d_bgc.reshape(s_bgc) if bg else None, None, None, None, None, None, None)
+
+
 def any_requires_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
 

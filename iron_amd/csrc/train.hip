@@ -770,9 +770,156 @@ __global__ void k_composite_back(CompBackArgs a) {
     }
 }
 
+// ---- NeuS compositing (models/renderer.py:279-344 + :174-178), reverse pass ------------------------------------------------------
+// One thread per ray: the forward is replayed keeping alpha_j and the transmittance T_j of the row (<= 192 samples), then a
+// reverse scan turns dL/dw_j into dL/dalpha_j (w_j = alpha_j T_j, T_{j+1} = T_j (1 - alpha_j + 1e-7)) and from there into
+// dL/d(sdf, gradient, sample colour, 1/s, background density / colour).
+constexpr int kNeusMax = 192;
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct NeusBackArgs {
+    iron_neus_composite_args f;  // the forward's inputs (outputs unused)
+    const float *d_color, *d_weight_sum, *d_weights, *d_gradient_error, *relax_count;
+    float *d_sdf, *d_grad, *d_sample_color, *d_inv_s, *d_bg_density, *d_bg_color;
+};
+
+__global__ void k_neus_composite_back(NeusBackArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const iron_neus_composite_args& f = a.f;
+    float dinv_acc = 0.0f;
+    if (r < f.n) {
+        const bool bg = f.bg_density != nullptr;
+        const int m = f.m, mt = bg ? f.mo : f.m;
+        float al[kNeusMax], T[kNeusMax];
+        float trans = 1.0f;
+        for (int j = 0; j < mt; ++j) {  // forward replay: composited alpha and transmittance
+            float alpha, bga = 0.0f;
+            if (bg) {
+                const size_t q = (size_t)r * f.mo + j;
+                const float d = f.bg_density[q];
+                bga = 1.0f - expf(-(d > 20.0f ? d : log1pf(expf(d))) * f.bg_dists[q]);
+            }
+            if (j < m) {
+                const size_t q = (size_t)r * m + j;
+                const float tc = (f.dirs[3 * q] * f.grad[3 * q] + f.dirs[3 * q + 1] * f.grad[3 * q + 1]) + f.dirs[3 * q + 2] * f.grad[3 * q + 2];
+                const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.0f) * (1.0f - f.cos_anneal_ratio) + fmaxf(-tc, 0.0f) * f.cos_anneal_ratio);
+                const float s = f.sdf[q], dist = f.dists[q];
+                const float pc = sigm((s - ic * dist * 0.5f) * f.inv_s), nc = sigm((s + ic * dist * 0.5f) * f.inv_s);
+                alpha = fminf(fmaxf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f), 1.0f);
+                if (bg) {
+                    const float px = f.pts[3 * q], py = f.pts[3 * q + 1], pz = f.pts[3 * q + 2];
+                    const float ins = sqrtf((px * px + py * py) + pz * pz) < 1.0f ? 1.0f : 0.0f;
+                    alpha = alpha * ins + bga * (1.0f - ins);
+                }
+            } else {
+                alpha = bga;
+            }
+            al[j] = alpha;
+            T[j] = trans;
+            trans = trans * (1.0f - alpha + 1e-7f);
+        }
+        const float dcol[3] = {a.d_color ? a.d_color[3 * (size_t)r] : 0.f, a.d_color ? a.d_color[3 * (size_t)r + 1] : 0.f,
+                               a.d_color ? a.d_color[3 * (size_t)r + 2] : 0.f};
+        const float dws = a.d_weight_sum ? a.d_weight_sum[r] : 0.0f;
+        float bgr[3] = {0.f, 0.f, 0.f};
+        if (f.background_rgb) { bgr[0] = f.background_rgb[0]; bgr[1] = f.background_rgb[1]; bgr[2] = f.background_rgb[2]; }
+        const float dge = a.d_gradient_error ? a.d_gradient_error[0] : 0.0f;
+        const float inv_cnt = a.relax_count ? 1.0f / (a.relax_count[0] + 1e-5f) : 0.0f;
+        float suffix = 0.0f;  // sum over k > j of Gw_k w_k
+        for (int j = mt - 1; j >= 0; --j) {
+            const float w = al[j] * T[j];
+            // the colour this sample contributed
+            float c[3], ins = 1.0f;
+            size_t q = 0, qb = (size_t)r * (bg ? f.mo : 1) + j;
+            if (j < m) {
+                q = (size_t)r * m + j;
+                if (bg) {
+                    const float px = f.pts[3 * q], py = f.pts[3 * q + 1], pz = f.pts[3 * q + 2];
+                    ins = sqrtf((px * px + py * py) + pz * pz) < 1.0f ? 1.0f : 0.0f;
+                }
+                for (int k = 0; k < 3; ++k) c[k] = bg ? f.color[3 * q + k] * ins + f.bg_color[3 * qb + k] * (1.0f - ins) : f.color[3 * q + k];
+            } else {
+                ins = 0.0f;
+                for (int k = 0; k < 3; ++k) c[k] = f.bg_color[3 * qb + k];
+            }
+            float Gw = dws + (a.d_weights ? a.d_weights[(size_t)r * mt + j] : 0.0f);
+            for (int k = 0; k < 3; ++k) Gw += dcol[k] * (c[k] - bgr[k]);
+            const float dalpha = Gw * T[j] - suffix / (1.0f - al[j] + 1e-7f);
+            suffix += Gw * w;
+            // colours
+            if (j < m && a.d_sample_color)
+                for (int k = 0; k < 3; ++k) a.d_sample_color[3 * q + k] = dcol[k] * w * ins;
+            if (bg && a.d_bg_color)
+                for (int k = 0; k < 3; ++k) a.d_bg_color[3 * qb + k] = dcol[k] * w * (1.0f - ins);
+            // background alpha -> density
+            if (bg && a.d_bg_density) {
+                const float d = f.bg_density[qb], bd = f.bg_dists[qb];
+                const float sp = d > 20.0f ? d : log1pf(expf(d));
+                const float dsp = d > 20.0f ? 1.0f : sigm(d);
+                a.d_bg_density[qb] = dalpha * (1.0f - ins) * expf(-sp * bd) * bd * dsp;
+            }
+            if (j < m) {
+                const float gx = f.grad[3 * q], gy = f.grad[3 * q + 1], gz = f.grad[3 * q + 2];
+                const float dx = f.dirs[3 * q], dy = f.dirs[3 * q + 1], dz = f.dirs[3 * q + 2];
+                const float tc = (dx * gx + dy * gy) + dz * gz;
+                const float ca = f.cos_anneal_ratio;
+                const float a1 = -tc * 0.5f + 0.5f, b1 = -tc;
+                const float ic = -(fmaxf(a1, 0.0f) * (1.0f - ca) + fmaxf(b1, 0.0f) * ca);
+                const float s = f.sdf[q], dist = f.dists[q];
+                const float ep = s - ic * dist * 0.5f, en = s + ic * dist * 0.5f;
+                const float pc = sigm(ep * f.inv_s), nc = sigm(en * f.inv_s);
+                const float araw = (pc - nc + 1e-5f) / (pc + 1e-5f);
+                const float da = (araw >= 0.0f && araw <= 1.0f) ? dalpha * ins : 0.0f;
+                const float ipc = 1.0f / (pc + 1e-5f);
+                const float dpc = da * (ipc - araw * ipc), dnc = -da * ipc;
+                const float dup = dpc * pc * (1.0f - pc), dun = dnc * nc * (1.0f - nc);
+                dinv_acc += dup * ep + dun * en;
+                const float dep = dup * f.inv_s, den = dun * f.inv_s;
+                if (a.d_sdf) a.d_sdf[q] = dep + den;
+                const float dic = (den - dep) * dist * 0.5f;
+                const float dtc = dic * ((a1 > 0.0f ? 0.5f * (1.0f - ca) : 0.0f) + (b1 > 0.0f ? ca : 0.0f));
+                float dg[3] = {dtc * dx, dtc * dy, dtc * dz};
+                if (dge != 0.0f) {  // eikonal statistic: sum relax (|g|-1)^2 / (sum relax + 1e-5)
+                    const float px = f.pts[3 * q], py = f.pts[3 * q + 1], pz = f.pts[3 * q + 2];
+                    if (sqrtf((px * px + py * py) + pz * pz) < 1.2f) {
+                        const float gn = sqrtf((gx * gx + gy * gy) + gz * gz);
+                        const float k = dge * inv_cnt * 2.0f * (gn - 1.0f) / gn;
+                        dg[0] += k * gx; dg[1] += k * gy; dg[2] += k * gz;
+                    }
+                }
+                if (a.d_grad) { a.d_grad[3 * q] = dg[0]; a.d_grad[3 * q + 1] = dg[1]; a.d_grad[3 * q + 2] = dg[2]; }
+            }
+        }
+    }
+    if (a.d_inv_s) {
+        for (int o = 32; o > 0; o >>= 1) dinv_acc += __shfl_xor(dinv_acc, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.d_inv_s, dinv_acc);
+    }
+}
+
 }  // namespace iron_train
 
 using namespace iron_train;
+
+extern "C" int iron_neus_composite_backward(const iron_neus_composite_args* fwd, const iron_neus_composite_grads* g, void* stream) {
+    if (!fwd || !g || fwd->n < 0 || fwd->m < 1 || fwd->m > kNeusMax) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (g->d_inv_s) TR_HIP(hipMemsetAsync(g->d_inv_s, 0, sizeof(float), st));
+    if (fwd->n == 0) return IRON_OK;
+    if (!fwd->dists || !fwd->pts || !fwd->dirs || !fwd->sdf || !fwd->grad || !fwd->color) return IRON_ERR_BAD_ARG;
+    if (fwd->bg_density && (!fwd->bg_dists || !fwd->bg_color || fwd->mo < fwd->m || fwd->mo > kNeusMax)) return IRON_ERR_BAD_ARG;
+    if (g->d_gradient_error && !g->relax_count) return IRON_ERR_BAD_ARG;
+    NeusBackArgs a;
+    a.f = *fwd;
+    a.d_color = g->d_color; a.d_weight_sum = g->d_weight_sum; a.d_weights = g->d_weights; a.d_gradient_error = g->d_gradient_error;
+    a.relax_count = g->relax_count;
+    a.d_sdf = g->d_sdf; a.d_grad = g->d_grad; a.d_sample_color = g->d_sample_color; a.d_inv_s = g->d_inv_s;
+    a.d_bg_density = g->d_bg_density; a.d_bg_color = g->d_bg_color;
+    hipLaunchKernelGGL(k_neus_composite_back, dim3((unsigned)((fwd->n + 63) / 64)), dim3(64), 0, st, a);
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
 
 extern "C" int iron_composite_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
                                                  const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,

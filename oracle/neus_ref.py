@@ -173,7 +173,19 @@ def render_core(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, s
     out, feat, grads = R.sdf_get_all(sc.sdf_sd, sc.sdf_spec, pts)
     sdf = out[:, :1]
     color = R.rendering_forward(sc.color_sd, sc.color_spec, pts, grads, dirs, feat).reshape(batch, n, 3)
-    inv_s = single_variance(sc.variance, 1)[:, :1].clip(1e-6, 1e6).expand(batch * n, 1)
+    inv_s = single_variance(sc.variance, 1)[:, :1].clip(1e-6, 1e6)
+    return composite(sdf, grads, color, dists, pts, dirs, inv_s, background_alpha, background_sampled_color, background_rgb, cos_anneal_ratio,
+                     mid)
+
+
+def composite(sdf: Tensor, grads: Tensor, color: Tensor, dists: Tensor, pts: Tensor, dirs: Tensor, inv_s: Tensor,
+              background_alpha: Optional[Tensor], background_sampled_color: Optional[Tensor], background_rgb: Optional[Tensor],
+              cos_anneal_ratio: float, mid: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """renderer.py:279-344: from the network outputs at the section mid points (sdf [b*n,1], grads [b*n,3], color [b,n,3]) to the
+    composited colour, weights and statistics.  Pure tensor math (differentiable): the product's compositing kernel and its
+    backward are tested against it."""
+    batch, n = dists.shape
+    inv_s = inv_s.reshape(1, 1).expand(batch * n, 1)
     true_cos = (dirs * grads).sum(-1, keepdim=True)
     iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-true_cos) * cos_anneal_ratio)
     est_next = sdf + iter_cos * dists.reshape(-1, 1) * 0.5

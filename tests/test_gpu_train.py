@@ -516,3 +516,51 @@ def test_composite_training_render_vs_oracle_autograd():
     print("composite training render: worst rel-L2 per net", {k: "%.1e" % v for k, v in worst.items()}, "d/dlight %.6g vs %.6g" % (lg, float(light.grad)))
     assert max(worst.values()) <= 2e-3
     assert abs(lg - float(light.grad)) <= 2e-4 * abs(float(light.grad))
+
+
+@pytest.mark.parametrize("with_bg,with_rgb", [(True, False), (False, True), (True, True)])
+def test_neus_composite_backward_vs_autograd(with_bg, with_rgb):
+    """The compositing of render_core (renderer.py:279-344) and its reverse scan vs torch.autograd over oracle.neus_ref.composite:
+    gradients w.r.t. sdf, normals, sample colours, 1/s and the background density / colour, from colour, weight_sum (the mask
+    loss) and the eikonal statistic."""
+    from iron_amd.autograd import NeusCompositeFn
+    from oracle import neus_ref as N
+    gen = torch.Generator().manual_seed(41)
+    n, m, mo = 193, 128, 160
+    z = torch.sort(torch.rand(n, mo, generator=gen) * 2.2 + 1.2, dim=-1)[0]
+    o = torch.tensor([[0.0, 0.0, -2.3]]).expand(n, 3)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen) * torch.tensor([0.25, 0.25, 0.0]) + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    zi = z[:, :m]
+    dists = torch.cat([zi[:, 1:] - zi[:, :-1], torch.full((n, 1), 2.0 / 64)], dim=-1)
+    pts = (o[:, None, :] + d[:, None, :] * (zi + dists * 0.5)[..., None]).reshape(-1, 3)
+    dirs = d[:, None, :].expand(n, m, 3).reshape(-1, 3)
+    bgd_ = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 2.0 / 64)], dim=-1)
+    ins = {"sdf": (pts.norm(dim=-1, keepdim=True) - 0.6 + 0.01 * torch.randn(n * m, 1, generator=gen)),
+           "grad": torch.nn.functional.normalize(pts, dim=-1) * (1 + 0.1 * torch.randn(n * m, 1, generator=gen)) + 0.05 * torch.randn(n * m, 3, generator=gen),
+           "color": torch.rand(n * m, 3, generator=gen), "inv_s": torch.tensor(37.0)}
+    if with_bg:
+        ins["bg_density"] = torch.randn(n * mo, 1, generator=gen)
+        ins["bg_color"] = torch.randn(n * mo, 3, generator=gen) * 0.5
+    bgrgb = torch.tensor([[0.2, 0.5, 0.9]]) if with_rgb else None
+    up_c, up_w, up_g = torch.randn(n, 3, generator=gen), torch.randn(n, 1, generator=gen), 0.7
+
+    v = {k: x.clone().requires_grad_(True) for k, x in ins.items()}
+    bga = bgc = None
+    if with_bg:
+        bga = (1.0 - torch.exp(-torch.nn.functional.softplus(v["bg_density"].reshape(n, mo)) * bgd_)).reshape(n, mo)
+        bgc = v["bg_color"].reshape(n, mo, 3)
+    ref = N.composite(v["sdf"], v["grad"], v["color"].reshape(n, m, 3), dists, pts, dirs, v["inv_s"], bga, bgc, bgrgb, 0.3)
+    ((ref["color"] * up_c).sum() + (ref["weights"].sum(dim=-1, keepdim=True) * up_w).sum() + up_g * ref["gradient_error"]).backward()
+
+    g = {k: x.clone().cuda().requires_grad_(True) for k, x in ins.items()}
+    col, w, wsum, gerr, cdf, inside, wmax = NeusCompositeFn.apply(g["sdf"], g["grad"], g["color"], g["inv_s"], g.get("bg_density"), g.get("bg_color"),
+                                                                  dists.cuda(), pts.cuda(), dirs.cuda(), bgd_.cuda() if with_bg else None,
+                                                                  bgrgb.cuda() if with_rgb else None, 0.3)
+    assert _rel(col.detach().cpu().numpy(), ref["color"].detach().numpy()) <= 1e-5
+    assert abs(float(gerr) - float(ref["gradient_error"])) <= 1e-5 * abs(float(ref["gradient_error"]))
+    assert not cdf.requires_grad and not wmax.requires_grad
+    ((col * up_c.cuda()).sum() + (wsum * up_w.cuda()).sum() + up_g * gerr).backward()
+    for k in ins:
+        r = _rel(g[k].grad.cpu().numpy(), v[k].grad.numpy())
+        print("neus composite (bg=%s rgb=%s) d/d%s rel-L2 %.2e" % (with_bg, with_rgb, k, r))
+        assert r <= 2e-4, (k, r)
