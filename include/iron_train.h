@@ -115,6 +115,22 @@ int iron_composite_colocated_backward(float light, const float* distance, const 
                                       const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
                                       const iron_composite_grads_in* upstream, const iron_composite_grads_out* out, void* stream);
 
+/* NeRF (models/fields.py:243-327, use_viewdirs=True): D ReLU layers of width W on PE(input_pts), `skip` = the layer after
+ * whose activation the encoded input is concatenated IN FRONT (fields.py:309-310; -1: none), then alpha (1), feature (W), one
+ * view layer on cat[feature, PE(views)] and rgb (3).  layers = the D point layers followed by alpha, feature, view, rgb; plain
+ * nn.Linear (weight_g NULL).  Backward: d_alpha [n,1] / d_rgb [n,3] (each nullable) -> parameter gradients; the inputs get
+ * none (the reference feeds sample positions computed without grad, renderer.py:163-172). */
+typedef struct iron_nerf_train_desc {
+    int32_t D, W;
+    int32_t d_in, d_in_view;
+    int32_t multires, multires_view;
+    int32_t skip;
+    const iron_train_layer* layers;
+} iron_nerf_train_desc;
+size_t iron_nerf_backward_workspace_bytes(const iron_nerf_train_desc* desc, int64_t n);
+int iron_nerf_backward(const iron_nerf_train_desc* desc, const float* pts, const float* views, int64_t n, const float* d_alpha,
+                       const float* d_rgb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of iron_neus_composite (the compositing of NeuSRenderer.render_core, models/renderer.py:279-344, with the
  * background blend of :174-178).  `fwd` = the forward call's argument block (its output pointers are ignored).  Upstream,
  * each nullable: d_color [n,3], d_weight_sum [n], d_weights [n, mo or m], d_gradient_error [1] (device; needs relax_count =

@@ -150,6 +150,11 @@ class iron_composite_grads_out(C.Structure):
                                           "d_specular_roughness", "d_metallic_eta", "d_metallic_k", "d_dielectric_eta")]
 
 
+class iron_nerf_train_desc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("d_in", C.c_int32), ("d_in_view", C.c_int32), ("multires", C.c_int32),
+                ("multires_view", C.c_int32), ("skip", C.c_int32), ("layers", C.POINTER(iron_train_layer))]
+
+
 class iron_neus_composite_grads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("d_color", "d_weight_sum", "d_weights", "d_gradient_error", "relax_count", "d_sdf", "d_grad",
                                           "d_sample_color", "d_inv_s", "d_bg_density", "d_bg_color")]
@@ -164,6 +169,8 @@ TRAIN_SYMBOLS = {
     "iron_ggx_colocated_backward": (C.c_int, [_F] + [_P] * 8 + [_I64] + [_P] * 10 + [_P]),
     "iron_composite_colocated_backward": (C.c_int, [_F, _P, _P, _P, C.POINTER(iron_composite_params), _P, _P, _I64,
                                                     C.POINTER(iron_composite_grads_in), C.POINTER(iron_composite_grads_out), _P]),
+    "iron_nerf_backward_workspace_bytes": (_SZ, [C.POINTER(iron_nerf_train_desc), _I64]),
+    "iron_nerf_backward": (C.c_int, [C.POINTER(iron_nerf_train_desc), _P, _P, _I64, _P, _P, _P, _SZ, _P]),
     "iron_neus_composite_backward": (C.c_int, [C.POINTER(iron_neus_composite_args), C.POINTER(iron_neus_composite_grads), _P]),
     "iron_train_last_hip_error": (C.c_int, []),
     "iron_train_last_blas_status": (C.c_int, []),

@@ -294,6 +294,48 @@ class CompositeFn(torch.autograd.Function):
                 d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(m.reshape(s) for m, s in zip(d_maps, ctx.shapes[5:]))
 
 
+class NeRFFn(torch.autograd.Function):
+    """(alpha [n,1], rgb [n,3]) = NeRF(input_pts [n,4], input_views [n,3]); differentiable w.r.t. the parameters (the reference
+    feeds sample positions computed without grad, renderer.py:163-172, so the inputs get none)."""
+
+    @staticmethod
+    def forward(ctx, net, pts, views, *params):
+        ctx.set_materialize_grads(False)
+        ctx.net = net
+        with torch.no_grad():
+            alpha, rgb = net._forward_values(pts, views)
+        ctx.save_for_backward(pts.detach(), views.detach())
+        return alpha, rgb
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_rgb):
+        net = ctx.net
+        pts, views = ctx.saved_tensors
+        pts = _lib.require_cuda_f32(pts, "input_pts").reshape(-1, net.d_in)
+        views = _lib.require_cuda_f32(views, "input_views").reshape(-1, net.d_in_view)
+        n = pts.shape[0]
+        dev = pts.device
+        lib = _lib.load_train()
+        with torch.cuda.device(dev):
+            arr, keep, grads = _train_layers(net, dev)
+            desc = _lib.iron_nerf_train_desc()
+            desc.D, desc.W, desc.d_in, desc.d_in_view = net.D, net.W, net.d_in, net.d_in_view
+            desc.multires, desc.multires_view = net.multires, net.multires_view
+            if len(net.skips) > 1:
+                raise _lib.IronError("NeRF backward supports at most one skip layer")
+            desc.skip = net.skips[0] if net.skips else -1
+            desc.layers = arr
+            nbytes = lib.iron_nerf_backward_workspace_bytes(C.byref(desc), n)
+            if nbytes == 0:
+                raise _lib.IronError("unsupported NeRF shape for the backward pass")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            d_alpha, d_rgb = _opt(d_alpha, (-1,)), _opt(d_rgb, (-1, 3))
+            _lib.check_train(lib.iron_nerf_backward(C.byref(desc), pts.data_ptr(), views.data_ptr(), n, _lib.ptr(d_alpha), _lib.ptr(d_rgb),
+                                                    ws.data_ptr(), nbytes, _lib.stream_ptr(dev)))
+        del keep
+        return (None, None, None) + tuple(grads)
+
+
 class NeusCompositeFn(torch.autograd.Function):
     """The compositing of NeuSRenderer.render_core (models/renderer.py:279-344, background blend :174-178) from the network
     outputs at the section mid points: (sdf [n*m,1], grad [n*m,3], colour [n*m,3], 1/s, background density / colour) ->

@@ -770,6 +770,172 @@ __global__ void k_composite_back(CompBackArgs a) {
     }
 }
 
+// ---- NeRF background field (models/fields.py:243-327), parameter gradients --------------------------------------------------------
+// PE of a `dims`-wide input: [x, sin(2^0 x), cos(2^0 x), ...], each block `dims` wide
+__device__ __forceinline__ float pe_val(const float* x, int c, int dims) {
+    if (c < dims) return x[c];
+    const int k = (c - dims) / (2 * dims), r = (c - dims) % (2 * dims);
+    const float a = x[r % dims] * (float)(1 << k);
+    return r < dims ? sinf(a) : cosf(a);
+}
+
+// dst[p, col0 + c] = PE(src[p, :dims])[c]
+__global__ void k_pe_rows(const float* __restrict__ src, int dims, int L, int m, float* __restrict__ dst, int ld, int col0) {
+    const int D = dims + 2 * dims * L;
+    GRID_STRIDE(i, (int64_t)m * D) {
+        const int p = (int)(i / D), c = (int)(i % D);
+        dst[(size_t)p * ld + col0 + c] = pe_val(src + (size_t)p * dims, c, dims);
+    }
+}
+
+// dst[p, c] = src[p, c] (+ bias[c]); db[c] += column sums of src when db != NULL  (strip form)
+__global__ void k_bias_copy_colsum(const float* __restrict__ src, int ld_src, const float* __restrict__ bias, int m, int out, float* __restrict__ dst,
+                                   int ld_dst, float* __restrict__ db) {
+    STRIP_PROLOGUE(m, out)
+    for (int p = r0; p < r1; ++p) {
+        const float v = src[(size_t)p * ld_src + c];
+        if (dst) dst[(size_t)p * ld_dst + c] = bias ? v + bias[c] : v;
+        colsum += v;
+    }
+    if (db) atomicAdd(&db[c], colsum);
+}
+
+// dst[p, 0:w) += a[p] * row[0:w)   (the alpha head's contribution to dL/dh: one output row)
+__global__ void k_add_outer(const float* __restrict__ a, const float* __restrict__ row, int m, int w, float* __restrict__ dst, int ld) {
+    GRID_STRIDE(i, (int64_t)m * w) {
+        const int p = (int)(i / w), c = (int)(i % w);
+        dst[(size_t)p * ld + c] += a[p] * row[c];
+    }
+}
+
+constexpr int kNerfChunk = 131072;
+
+struct NerfPlan {
+    int D, W, in_p, in_v, nl, m_max;
+    float *Wt[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *X[kMaxLayers], *Z[kMaxLayers];
+    float *HV, *ZV, *AV, *dA, *dB, *partial;
+    size_t bytes;
+};
+
+static int nerf_plan(const iron_nerf_train_desc* d, int64_t n, void* ws, NerfPlan& P) {
+    if (!d || !d->layers || d->D < 2 || d->D + 4 > kMaxLayers || d->W < 1 || d->d_in < 1 || d->d_in_view < 1) return IRON_ERR_BAD_ARG;
+    P.D = d->D; P.W = d->W; P.nl = d->D + 4;
+    P.in_p = d->d_in + 2 * d->d_in * (d->multires > 0 ? d->multires : 0);
+    P.in_v = d->d_in_view + 2 * d->d_in_view * (d->multires_view > 0 ? d->multires_view : 0);
+    const iron_train_layer* ly = d->layers;
+    for (int i = 0; i < d->D; ++i) {
+        const int expect = i == 0 ? P.in_p : (d->W + ((i - 1) == d->skip ? P.in_p : 0));
+        if (ly[i].in_dim != expect || ly[i].out_dim != d->W) return IRON_ERR_UNSUPPORTED;
+    }
+    const int hD = d->W + ((d->D - 1) == d->skip ? P.in_p : 0);
+    if (ly[d->D].in_dim != hD || ly[d->D].out_dim != 1) return IRON_ERR_UNSUPPORTED;                       // alpha
+    if (ly[d->D + 1].in_dim != hD || ly[d->D + 1].out_dim != d->W) return IRON_ERR_UNSUPPORTED;            // feature
+    if (ly[d->D + 2].in_dim != d->W + P.in_v) return IRON_ERR_UNSUPPORTED;                                  // view layer
+    if (ly[d->D + 3].in_dim != ly[d->D + 2].out_dim) return IRON_ERR_UNSUPPORTED;                           // rgb
+    P.m_max = (int)(n < kNerfChunk ? (n > 0 ? n : 1) : kNerfChunk);
+    const size_t R = (size_t)P.m_max;
+    Bump b(ws);
+    int maxw = 0;
+    for (int l = 0; l < P.nl; ++l) {
+        const size_t wn = (size_t)ly[l].out_dim * ly[l].in_dim;
+        P.Wt[l] = b.take(wn);
+        P.dW[l] = b.take(wn);
+        P.db[l] = b.take(ly[l].out_dim);
+        maxw = max(maxw, max(ly[l].out_dim, ly[l].in_dim));
+    }
+    for (int i = 0; i <= d->D; ++i) P.X[i] = b.take(R * (i < d->D ? ly[i].in_dim : hD));  // X[D] = h_D
+    for (int i = 0; i < d->D; ++i) P.Z[i] = b.take(R * d->W);
+    P.HV = b.take(R * ly[d->D + 2].in_dim);
+    P.ZV = b.take(R * ly[d->D + 2].out_dim);
+    P.AV = b.take(R * ly[d->D + 2].out_dim);
+    P.dA = b.take(R * maxw);
+    P.dB = b.take(R * maxw);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw);
+    P.bytes = b.off + 256;
+    return IRON_OK;
+}
+
+static int nerf_backward(const iron_nerf_train_desc* d, const float* pts, const float* views, int64_t n, const float* d_alpha, const float* d_rgb,
+                         void* ws, size_t ws_bytes, hipStream_t st) {
+    NerfPlan P;
+    TR_TRY(nerf_plan(d, n, ws, P));
+    if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
+    std::lock_guard<std::mutex> blas_lock(g_blas_use);
+    rocblas_handle h = blas_for_current_device();
+    if (!h) return IRON_ERR_HIP;
+    TR_BLAS(rocblas_set_stream(h, st));
+    const iron_train_layer* ly = d->layers;
+    const int D = P.D, W = P.W, iA = D, iF = D + 1, iV = D + 2, iC = D + 3;
+    const int wv = ly[iV].out_dim, hD = ly[iA].in_dim;
+    for (int l = 0; l < P.nl; ++l) {
+        hipLaunchKernelGGL(k_wn_fold, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, ly[l].out_dim, ly[l].in_dim, P.Wt[l]);
+        TR_HIP(hipMemsetAsync(P.db[l], 0, sizeof(float) * ly[l].out_dim, st));
+        if (n == 0 || (l == iA && !d_alpha) || ((l == iF || l == iV || l == iC) && !d_rgb))
+            TR_HIP(hipMemsetAsync(P.dW[l], 0, sizeof(float) * ly[l].out_dim * ly[l].in_dim, st));
+    }
+    for (int64_t p0 = 0; p0 < n; p0 += P.m_max) {
+        const int m = (int)((n - p0) < P.m_max ? (n - p0) : P.m_max);
+        const float beta = p0 == 0 ? 0.0f : 1.0f;
+        // ---- forward, keeping every layer's input and pre-activation
+        hipLaunchKernelGGL(k_pe_rows, grid1((int64_t)m * P.in_p), dim3(256), 0, st, pts + (size_t)p0 * d->d_in, d->d_in, d->multires > 0 ? d->multires : 0, m,
+                           P.X[0], P.in_p, 0);
+        for (int i = 0; i < D; ++i) {
+            const int in = ly[i].in_dim;
+            TR_TRY(gemm_rm(h, false, true, m, W, in, P.X[i], in, P.Wt[i], in, 0.0f, P.Z[i], W));
+            const bool skip = (i == d->skip);
+            const int ld_next = i + 1 < D ? ly[i + 1].in_dim : hD;
+            const int off = skip ? P.in_p : 0;
+            hipLaunchKernelGGL(k_relu_act, grid1((int64_t)m * W), dim3(256), 0, st, P.Z[i], ly[i].bias, m, W, 1.0f, P.X[i + 1] + off, ld_next);
+            if (skip) hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)m * P.in_p), dim3(256), 0, st, P.X[0], P.in_p, m, P.in_p, 1.0f, P.X[i + 1], ld_next, 0);
+        }
+        if (d_rgb) {
+            const int inv = ly[iV].in_dim;
+            TR_TRY(gemm_rm(h, false, true, m, W, hD, P.X[D], hD, P.Wt[iF], hD, 0.0f, P.dA, W));  // feature (pre-bias) in dA
+            hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, W), dim3(256), 0, st, P.dA, W, ly[iF].bias, m, W, P.HV, inv, (float*)nullptr);
+            hipLaunchKernelGGL(k_pe_rows, grid1((int64_t)m * P.in_v), dim3(256), 0, st, views + (size_t)p0 * d->d_in_view, d->d_in_view,
+                               d->multires_view > 0 ? d->multires_view : 0, m, P.HV, inv, W);
+            TR_TRY(gemm_rm(h, false, true, m, wv, inv, P.HV, inv, P.Wt[iV], inv, 0.0f, P.ZV, wv));
+            hipLaunchKernelGGL(k_relu_act, grid1((int64_t)m * wv), dim3(256), 0, st, P.ZV, ly[iV].bias, m, wv, 1.0f, P.AV, wv);
+        }
+        // ---- reverse
+        TR_HIP(hipMemsetAsync(P.dA, 0, sizeof(float) * (size_t)m * hD, st));  // dA = dL/dh_D
+        if (d_rgb) {
+            const float* g = d_rgb + (size_t)p0 * 3;
+            const int inv = ly[iV].in_dim;
+            TR_TRY(gemm_dw(h, st, 3, wv, m, g, P.AV, beta, P.dW[iC], P.partial));
+            hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, 3), dim3(256), 0, st, g, 3, (const float*)nullptr, m, 3, (float*)nullptr, 0, P.db[iC]);
+            TR_TRY(gemm_rm(h, false, false, m, wv, 3, g, 3, P.Wt[iC], wv, 0.0f, P.dB, wv));                               // dL/d av
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, wv), dim3(256), 0, st, P.dB, wv, P.ZV, m, wv, 1.0f, P.AV, P.db[iV]);  // AV <- dL/d zv
+            TR_TRY(gemm_dw(h, st, wv, inv, m, P.AV, P.HV, beta, P.dW[iV], P.partial));
+            TR_TRY(gemm_rm(h, false, false, m, inv, wv, P.AV, wv, P.Wt[iV], inv, 0.0f, P.dB, inv));                        // dL/d hv; [:, :W] = dL/d feature
+            hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, W), dim3(256), 0, st, P.dB, inv, (const float*)nullptr, m, W, P.HV, W, P.db[iF]);                                                                                // HV[:, :W] (ld W) <- dL/d feature
+            TR_TRY(gemm_dw(h, st, W, hD, m, P.HV, P.X[D], beta, P.dW[iF], P.partial));
+            TR_TRY(gemm_rm(h, false, false, m, hD, W, P.HV, W, P.Wt[iF], hD, 0.0f, P.dA, hD));
+        }
+        if (d_alpha) {
+            const float* g = d_alpha + p0;
+            TR_TRY(gemm_dw(h, st, 1, hD, m, g, P.X[D], beta, P.dW[iA], P.partial));
+            hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, 1), dim3(256), 0, st, g, 1, (const float*)nullptr, m, 1, (float*)nullptr, 0, P.db[iA]);
+            hipLaunchKernelGGL(k_add_outer, grid1((int64_t)m * hD), dim3(256), 0, st, g, P.Wt[iA], m, hD, P.dA, hD);
+        }
+        for (int i = D - 1; i >= 0; --i) {
+            const int in = ly[i].in_dim;
+            const int ld = i + 1 < D ? ly[i + 1].in_dim : hD;
+            const int off = (i == d->skip) ? P.in_p : 0;
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, W), dim3(256), 0, st, P.dA + off, ld, P.Z[i], m, W, 1.0f, P.dB, P.db[i]);  // dB = dL/d z_i
+            TR_TRY(gemm_dw(h, st, W, in, m, P.dB, P.X[i], beta, P.dW[i], P.partial));
+            if (i > 0) TR_TRY(gemm_rm(h, false, false, m, in, W, P.dB, W, P.Wt[i], in, 0.0f, P.dA, in));
+        }
+    }
+    for (int l = 0; l < P.nl; ++l) {
+        hipLaunchKernelGGL(k_wn_back, dim3(ly[l].out_dim), dim3(64), 0, st, ly[l].weight_v, ly[l].weight_g, P.dW[l], ly[l].out_dim, ly[l].in_dim,
+                           ly[l].d_weight_v, ly[l].d_weight_g);
+        TR_HIP(hipMemcpyAsync(ly[l].d_bias, P.db[l], sizeof(float) * ly[l].out_dim, hipMemcpyDeviceToDevice, st));
+    }
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
 // ---- NeuS compositing (models/renderer.py:279-344 + :174-178), reverse pass ------------------------------------------------------
 // One thread per ray: the forward is replayed keeping alpha_j and the transmittance T_j of the row (<= 192 samples), then a
 // reverse scan turns dL/dw_j into dL/dalpha_j (w_j = alpha_j T_j, T_{j+1} = T_j (1 - alpha_j + 1e-7)) and from there into
@@ -900,6 +1066,18 @@ __global__ void k_neus_composite_back(NeusBackArgs a) {
 }  // namespace iron_train
 
 using namespace iron_train;
+
+extern "C" size_t iron_nerf_backward_workspace_bytes(const iron_nerf_train_desc* desc, int64_t n) {
+    NerfPlan P;
+    if (n < 0 || nerf_plan(desc, n, nullptr, P) != IRON_OK) return 0;
+    return P.bytes;
+}
+
+extern "C" int iron_nerf_backward(const iron_nerf_train_desc* desc, const float* pts, const float* views, int64_t n, const float* d_alpha,
+                                  const float* d_rgb, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || !workspace || (n > 0 && (!pts || !views))) return IRON_ERR_BAD_ARG;
+    return nerf_backward(desc, pts, views, n, d_alpha, d_rgb, workspace, workspace_bytes, (hipStream_t)stream);
+}
 
 extern "C" int iron_neus_composite_backward(const iron_neus_composite_args* fwd, const iron_neus_composite_grads* g, void* stream) {
     if (!fwd || !g || fwd->n < 0 || fwd->m < 1 || fwd->m > kNeusMax) return IRON_ERR_BAD_ARG;

@@ -355,10 +355,17 @@ class NeRF(_HipNet):
         return d
 
     def forward(self, input_pts, input_views):
-        """[...,4], [...,3] -> (alpha [...,1], rgb [...,3])  (fields.py:299-325).  Forward only: under grad mode with anything that
-        requires grad it raises instead of returning detached values."""
-        from .autograd import refuse_grad
-        refuse_grad("NeRF.forward", input_pts, input_views, *self.parameters())
+        """[...,4], [...,3] -> (alpha [...,1], rgb [...,3])  (fields.py:299-325).  Under grad mode the outputs are attached to the
+        parameters (HIP forward + iron_nerf_backward); inputs that require grad are refused (no input gradient is built: the
+        reference feeds positions computed without grad)."""
+        from .autograd import NeRFFn, _layer_params, any_requires_grad, refuse_grad
+        refuse_grad("NeRF.forward w.r.t. its inputs", input_pts, input_views)
+        params = _layer_params(self)
+        if any_requires_grad(*params):
+            return NeRFFn.apply(self, input_pts, input_views, *params)
+        return self._forward_values(input_pts, input_views)
+
+    def _forward_values(self, input_pts, input_views):
         p = _lib.require_cuda_f32(input_pts.detach(), "input_pts")
         sh = list(p.shape[:-1])
         p = p.reshape(-1, 4)

@@ -146,10 +146,11 @@ def test_heads_without_a_backward_refuse_inputs_that_require_grad():
     from iron_amd.renderer_ggx import CompositeRenderer
     z = torch.rand(8, 3, device="cuda")
     nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True).cuda()
-    with pytest.raises(NotImplementedError):
-        nerf(torch.rand(8, 4, device="cuda"), z)
+    with pytest.raises(NotImplementedError):  # no gradient w.r.t. the sample positions is built
+        nerf(torch.rand(8, 4, device="cuda", requires_grad=True), z)
+    assert nerf(torch.rand(8, 4, device="cuda"), z)[0].requires_grad  # attached to the parameters (iron_nerf_backward)
     with torch.no_grad():
-        nerf(torch.rand(8, 4, device="cuda"), z)
+        assert not nerf(torch.rand(8, 4, device="cuda"), z)[0].requires_grad
     kd = torch.rand(8, 3, device="cuda", requires_grad=True)
     one = torch.rand(8, 1, device="cuda")
     from iron_amd.renderer_ggx import SmoothDielectricRenderer

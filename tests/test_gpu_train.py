@@ -564,3 +564,28 @@ def test_neus_composite_backward_vs_autograd(with_bg, with_rgb):
         r = _rel(g[k].grad.cpu().numpy(), v[k].grad.numpy())
         print("neus composite (bg=%s rgb=%s) d/d%s rel-L2 %.2e" % (with_bg, with_rgb, k, r))
         assert r <= 2e-4, (k, r)
+
+
+def test_nerf_backward_vs_autograd():
+    """NeRF background field (fields.py:243-327): parameter gradients from alpha and rgb vs torch.autograd over the oracle, at a
+    size that takes the split-K path, and from one head only."""
+    from iron_amd.fields import NeRF
+    from oracle import neus_ref as N
+    from oracle import train_ref as T
+    torch.manual_seed(5)
+    mod = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)
+    net_sd = cpu_sd(mod)
+    net = mod.cuda()
+    gen = torch.Generator().manual_seed(6)
+    for n, heads in ((4603, "ar"), (257, "a"), (257, "r")):
+        pts = torch.rand(n, 4, generator=gen) * 2 - 1
+        views = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        ua, ur = torch.randn(n, 1, generator=gen), torch.randn(n, 3, generator=gen)
+        sd = T.leaf_state(net_sd)
+        alpha, rgb = N.nerf_forward(sd, N.NerfSpec(), pts, views)
+        ((alpha * ua).sum() * ("a" in heads) + (rgb * ur).sum() * ("r" in heads)).backward()
+        a2, r2 = net(pts.cuda(), views.cuda())
+        assert a2.requires_grad and _rel(r2.detach().cpu().numpy(), rgb.detach().numpy()) <= 1e-5
+        ((a2 * ua.cuda()).sum() * ("a" in heads) + (r2 * ur.cuda()).sum() * ("r" in heads)).backward()
+        w = _compare_param_grads(net, sd, 2e-4, "nerf n=%d %s" % (n, heads))
+        print("nerf backward n=%d heads=%s worst rel-L2 %.2e (%s)" % (n, heads, w, getattr(_compare_param_grads, "last", "")))
