@@ -3,7 +3,8 @@
 `NeuSRenderer.render` keeps the reference's signature and output dictionary.  Every array stage runs as a HIP kernel
 behind the C ABI: sample placement, hierarchical up-sampling (inverse CDF), sorted merges and compositing are the
 per-ray kernels of csrc/neus.hip; the network evaluations between them are the batched SDF / colour / NeRF kernels the
-field classes of `iron_amd.fields` already front.  Forward only (no autograd graph): training is row f-2.
+field classes of `iron_amd.fields` already front.  Under grad mode with trainable networks the render cores are attached
+to the parameters (iron_amd.autograd), so the reference's stage-1 loss.backward() works.
 There is no CPU path -- tensors must live on the GPU and the HIP library must load.
 """
 from __future__ import annotations
@@ -146,13 +147,22 @@ class NeuSRenderer:
                                 query_func=lambda pts: -self.sdf_network.sdf(pts))
 
     # ---- render ---------------------------------------------------------------------------------------------------
-    @torch.no_grad()
+    def _trainable(self) -> bool:
+        from .autograd import any_requires_grad
+        params = []
+        for net in (self.sdf_network, self.color_network, self.nerf, self.deviation_network):
+            if net is not None:
+                params += list(net.parameters())
+        return any_requires_grad(*params)
+
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0) -> Dict[str, torch.Tensor]:
-        """renderer.py:346-453, perturb = 0 (the validation / deterministic path)."""
+        """renderer.py:346-453.  The sample placement (linspace, optional stratified jitter, the four up-sampling rounds, merges)
+        runs without grad exactly as in the reference (:387); under grad mode with trainable networks the two render cores are
+        attached to the parameters -- get_all / colour net / NeRF / compositing are the differentiable operators of
+        iron_amd.autograd -- so render_volume.py's loss.backward() works; otherwise plain tensors come back."""
+        from .autograd import NeusCompositeFn
+        training = self._trainable()
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
-        if perturb > 0:
-            raise NotImplementedError("iron_amd.NeuSRenderer renders the deterministic path (perturb = 0); stratified jitter "
-                                      "belongs to the training loop (SURVEY 8 row f-2)")
         rays_o, rays_d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
         dev = rays_o.device
         batch = rays_o.shape[0]
@@ -161,56 +171,57 @@ class NeuSRenderer:
         lib = _lib.load()
         sample_dist = 2.0 / self.n_samples
         with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            lin, rev = self._constants(dev)
-            z_vals = torch.empty((batch, self.n_samples), dtype=torch.float32, device=dev)
-            _lib.check(lib.iron_neus_linspace(near.data_ptr(), far.data_ptr(), lin.data_ptr(), batch, self.n_samples, z_vals.data_ptr(), st))
-            n_samples = self.n_samples
-            if self.n_importance > 0:
-                sdf = self.sdf_network.sdf(self._points(rays_o, rays_d, z_vals)).reshape(batch, self.n_samples)
-                for i in range(self.up_sample_steps):
-                    new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, self.n_importance // self.up_sample_steps, 64 * 2 ** i)
-                    z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
-                n_samples = self.n_samples + self.n_importance
+            with torch.no_grad():
+                st = _lib.stream_ptr(dev)
+                lin, rev = self._constants(dev)
+                z_vals = torch.empty((batch, self.n_samples), dtype=torch.float32, device=dev)
+                _lib.check(lib.iron_neus_linspace(near.data_ptr(), far.data_ptr(), lin.data_ptr(), batch, self.n_samples, z_vals.data_ptr(), st))
+                z_out = None
+                if perturb > 0:  # :369-378 (random numbers come from torch's generator of this device)
+                    z_vals = z_vals + (torch.rand([batch, 1], device=dev) - 0.5) * 2.0 / self.n_samples
+                if self.n_outside > 0:
+                    z_out = torch.empty((batch, self.n_outside), dtype=torch.float32, device=dev)
+                    if perturb > 0:
+                        zo = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
+                        mids = 0.5 * (zo[1:] + zo[:-1])
+                        upper, lower = torch.cat([mids, zo[-1:]], -1), torch.cat([zo[:1], mids], -1)
+                        zo = lower[None, :] + (upper - lower)[None, :] * torch.rand([batch, self.n_outside], device=dev)
+                        z_out = far[:, None] / torch.flip(zo, dims=[-1]) + 1.0 / self.n_samples
+                    else:
+                        # far / flip(linspace(1e-3, 1 - 1/(n_outside+1))) + 1/n_samples: one ascending row per ray (:361-381)
+                        _lib.check(lib.iron_neus_outside_z(far.data_ptr(), rev.data_ptr(), batch, self.n_outside, 1.0 / self.n_samples,
+                                                           z_out.data_ptr(), st))
+                n_samples = self.n_samples
+                if self.n_importance > 0:
+                    sdf = self.sdf_network.sdf(self._points(rays_o, rays_d, z_vals)).reshape(batch, self.n_samples)
+                    for i in range(self.up_sample_steps):
+                        new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, self.n_importance // self.up_sample_steps, 64 * 2 ** i)
+                        z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
+                    n_samples = self.n_samples + self.n_importance
+                bg_dists = bg_pts = bg_dirs = None
+                if self.n_outside > 0:
+                    z_feed, _ = self._merge(z_vals, None, z_out.contiguous(), None)
+                    bg_dists, bg_pts, bg_dirs = self._mid_points(rays_o, rays_d, z_feed, sample_dist, True)
+                dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, False)
 
-            a = _lib.iron_neus_composite_args()
-            keep = []
-            if self.n_outside > 0:
-                # far / flip(linspace(1e-3, 1 - 1/(n_outside+1))) + 1/n_samples: one ascending row per ray (:361-381)
-                z_out = torch.empty((batch, self.n_outside), dtype=torch.float32, device=dev)
-                _lib.check(lib.iron_neus_outside_z(far.data_ptr(), rev.data_ptr(), batch, self.n_outside, 1.0 / self.n_samples,
-                                                   z_out.data_ptr(), st))
-                z_feed, _ = self._merge(z_vals, None, z_out, None)
-                bg_dists, bg_pts, bg_dirs = self._mid_points(rays_o, rays_d, z_feed, sample_dist, True)
-                density, bg_color = self.nerf(bg_pts, bg_dirs)
-                density, bg_color = density.contiguous(), bg_color.contiguous()
-                keep += [bg_dists, density, bg_color]
-                a.bg_dists, a.bg_density, a.bg_color = bg_dists.data_ptr(), density.data_ptr(), bg_color.data_ptr()
-                a.mo = z_feed.shape[1]
-            dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, False)
-            sdf, feat, grad = self.sdf_network.get_all(pts, is_training=False)
-            color = self.color_network(pts, grad, dirs, feat).contiguous()
-            inv_s = self._inverse_s(dev)
-            n_tot = a.mo if self.n_outside > 0 else n_samples
-            out_color = torch.empty((batch, 3), dtype=torch.float32, device=dev)
-            weights = torch.empty((batch, n_tot), dtype=torch.float32, device=dev)
-            cdf = torch.empty((batch, n_samples), dtype=torch.float32, device=dev)
-            inside = torch.empty((batch, n_samples), dtype=torch.float32, device=dev)
-            wsum = torch.empty((batch, 1), dtype=torch.float32, device=dev)
-            wmax = torch.empty((batch, 1), dtype=torch.float32, device=dev)
-            gacc = torch.zeros(2, dtype=torch.float32, device=dev)
-            bgc = _f32(background_rgb, "background_rgb").reshape(3) if background_rgb is not None else None
-            a.dists, a.pts, a.dirs, a.sdf, a.grad, a.color = (t.data_ptr() for t in (dists, pts, dirs, sdf, grad, color))
-            a.background_rgb = _lib.ptr(bgc)
-            a.n, a.m = batch, n_samples
-            a.inv_s, a.cos_anneal_ratio = inv_s, float(cos_anneal_ratio)
-            a.out_color, a.weights, a.cdf, a.inside_sphere = out_color.data_ptr(), weights.data_ptr(), cdf.data_ptr(), inside.data_ptr()
-            a.weight_sum, a.weight_max, a.gradient_error_acc = wsum.data_ptr(), wmax.data_ptr(), gacc.data_ptr()
-            _lib.check(lib.iron_neus_composite(C.byref(a), st))
-            gradient_error = gacc[0] / (gacc[1] + 1e-5)
+            # render_core_outside (:151-187) and render_core (:250-344): attached to the parameters when training
+            with torch.set_grad_enabled(training):
+                density = bg_color = None
+                if self.n_outside > 0:
+                    density, bg_color = self.nerf(bg_pts, bg_dirs)
+                sdf, feat, grad = self.sdf_network.get_all(pts, is_training=training)
+                color = self.color_network(pts, grad, dirs, feat)
+                if training:
+                    inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6)
+                    s_val = (1.0 / inv_s).reshape(1, 1).expand(batch, 1)
+                else:
+                    inv_s = self._inverse_s(dev)
+                    s_val = torch.full((batch, 1), 1.0 / inv_s, dtype=torch.float32, device=dev)
+                out_color, weights, wsum, gradient_error, cdf, inside, wmax = NeusCompositeFn.apply(
+                    sdf, grad, color, inv_s, density, bg_color, dists, pts, dirs, bg_dists, background_rgb, float(cos_anneal_ratio))
         return {
             "color_fine": out_color,
-            "s_val": torch.full((batch, 1), 1.0 / inv_s, dtype=torch.float32, device=dev),
+            "s_val": s_val,
             "cdf_fine": cdf,
             "weight_sum": wsum,
             "weight_max": wmax,

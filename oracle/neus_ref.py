@@ -162,16 +162,20 @@ def render_core_outside(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, z_vals: T
 
 def render_core(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, sample_dist: float,
                 background_alpha: Optional[Tensor], background_sampled_color: Optional[Tensor],
-                background_rgb: Optional[Tensor], cos_anneal_ratio: float) -> Dict[str, Tensor]:
-    """renderer.py:250-344."""
+                background_rgb: Optional[Tensor], cos_anneal_ratio: float, training: bool = False) -> Dict[str, Tensor]:
+    """renderer.py:250-344.  training=True keeps the graph through sdf_network.gradient (create_graph=True, fields.py:106-118)."""
     batch, n = z_vals.shape
     dists = z_vals[..., 1:] - z_vals[..., :-1]
     dists = torch.cat([dists, torch.Tensor([sample_dist]).expand(dists[..., :1].shape)], -1)
     mid = z_vals + dists * 0.5
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid[..., :, None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(batch, n, 3).reshape(-1, 3)
-    out, feat, grads = R.sdf_get_all(sc.sdf_sd, sc.sdf_spec, pts)
-    sdf = out[:, :1]
+    if training:
+        from .train_ref import sdf_get_all_train
+        sdf, feat, grads = sdf_get_all_train(sc.sdf_sd, sc.sdf_spec, pts)
+    else:
+        out, feat, grads = R.sdf_get_all(sc.sdf_sd, sc.sdf_spec, pts)
+        sdf = out[:, :1]
     color = R.rendering_forward(sc.color_sd, sc.color_spec, pts, grads, dirs, feat).reshape(batch, n, 3)
     inv_s = single_variance(sc.variance, 1)[:, :1].clip(1e-6, 1e6)
     return composite(sdf, grads, color, dists, pts, dirs, inv_s, background_alpha, background_sampled_color, background_rgb, cos_anneal_ratio,
@@ -218,6 +222,19 @@ def composite(sdf: Tensor, grads: Tensor, color: Tensor, dists: Tensor, pts: Ten
 def render(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, near: Tensor, far: Tensor, background_rgb: Optional[Tensor] = None,
            cos_anneal_ratio: float = 0.0) -> Dict[str, Tensor]:
     """renderer.py:346-453 with perturb = 0."""
+    return _render(sc, rays_o, rays_d, near, far, background_rgb, cos_anneal_ratio, training=False)
+
+
+def render_train(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, near: Tensor, far: Tensor, background_rgb: Optional[Tensor] = None,
+                 cos_anneal_ratio: float = 0.0) -> Dict[str, Tensor]:
+    """The same under autograd, as render_volume.py:160-200 uses it (perturb = 0): the hierarchical sampling runs without grad
+    (renderer.py:387-409), render_core_outside and render_core with it.  `sc`'s state dicts / variance must be leaves that require
+    grad (oracle.train_ref.leaf_state)."""
+    return _render(sc, rays_o, rays_d, near, far, background_rgb, cos_anneal_ratio, training=True)
+
+
+def _render(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, near: Tensor, far: Tensor, background_rgb: Optional[Tensor],
+            cos_anneal_ratio: float, training: bool) -> Dict[str, Tensor]:
     batch = len(rays_o)
     sample_dist = 2.0 / sc.n_samples
     z_vals = near + (far - near) * torch.linspace(0.0, 1.0, sc.n_samples)[None, :]
@@ -227,18 +244,19 @@ def render(sc: NeusScene, rays_o: Tensor, rays_d: Tensor, near: Tensor, far: Ten
         z_out = far / torch.flip(z_out, dims=[-1]) + 1.0 / sc.n_samples
     n = sc.n_samples
     if sc.n_importance > 0:
-        pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., :, None]
-        sdf = sc.sdf(pts.reshape(-1, 3)).reshape(batch, sc.n_samples)
-        for i in range(sc.up_sample_steps):
-            new_z = up_sample(rays_o, rays_d, z_vals, sdf, sc.n_importance // sc.up_sample_steps, 64 * 2 ** i)
-            z_vals, sdf = cat_z_vals(sc, rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == sc.up_sample_steps))
+        with torch.no_grad():  # renderer.py:387
+            pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., :, None]
+            sdf = sc.sdf(pts.reshape(-1, 3)).reshape(batch, sc.n_samples)
+            for i in range(sc.up_sample_steps):
+                new_z = up_sample(rays_o, rays_d, z_vals, sdf, sc.n_importance // sc.up_sample_steps, 64 * 2 ** i)
+                z_vals, sdf = cat_z_vals(sc, rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == sc.up_sample_steps))
         n = sc.n_samples + sc.n_importance
     bg_alpha = bg_color = None
     if sc.n_outside > 0:
         z_feed, _ = torch.sort(torch.cat([z_vals, z_out], dim=-1), dim=-1)
         ro = render_core_outside(sc, rays_o, rays_d, z_feed, sample_dist)
         bg_color, bg_alpha = ro["sampled_color"], ro["alpha"]
-    fine = render_core(sc, rays_o, rays_d, z_vals, sample_dist, bg_alpha, bg_color, background_rgb, cos_anneal_ratio)
+    fine = render_core(sc, rays_o, rays_d, z_vals, sample_dist, bg_alpha, bg_color, background_rgb, cos_anneal_ratio, training=training)
     w = fine["weights"]
     return {"color_fine": fine["color"], "s_val": fine["s_val"].reshape(batch, n).mean(dim=-1, keepdim=True),
             "cdf_fine": fine["cdf"], "weight_sum": w.sum(dim=-1, keepdim=True), "weight_max": torch.max(w, dim=-1, keepdim=True)[0],

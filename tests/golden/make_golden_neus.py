@@ -42,6 +42,45 @@ def build_stage1(seed: int = 0):
     return nets
 
 
+def train():
+    """G16: the reference's NeuSRenderer.render under autograd (perturb = 0, as render_volume.py:160-200 forms its loss): colour,
+    eikonal statistic and weight_sum in a fixed loss; gradient norm + 48 sampled entries of EVERY parameter tensor of the four
+    stage-1 networks."""
+    import make_golden_train as MT
+    nets = build_stage1()
+    cam = MG.fixture_camera(512, 512)
+    uv = cam.get_uv()[16::44, 30::64].reshape(-1, 2).contiguous()
+    rays_o, rays_d, _ = cam.get_rays(uv)
+    a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+    b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    near, far = mid - 1.0, mid + 1.0
+    renderer = NeuSRenderer(nets["nerf"], nets["sdf_network"], nets["deviation_network"], nets["color_network"],
+                            n_samples=64, n_importance=64, n_outside=32, up_sample_steps=4, perturb=0.0)
+    out = renderer.render(rays_o, rays_d, near, far, perturb_overwrite=0, background_rgb=None, cos_anneal_ratio=0.3)
+    gen = torch.Generator().manual_seed(35)
+    wc, ww = torch.rand(96, 3, generator=gen) - 0.3, torch.rand(96, 1, generator=gen) - 0.5
+    loss = (out["color_fine"] * wc).sum() + 0.1 * out["gradient_error"] + (out["weight_sum"] * ww).sum()
+    loss.backward()
+    g = {"loss_wc": npf(wc), "loss_ww": npf(ww), "loss": np.float64(loss.item()), "color_fine": npf(out["color_fine"].detach()),
+         "weight_sum": npf(out["weight_sum"].detach()), "gradient_error": npf(out["gradient_error"].detach())}
+    n_params = 0
+    for name in sorted(nets):
+        for pname, p in nets[name].named_parameters():
+            assert p.grad is not None, (name, pname)
+            gr = p.grad.reshape(-1).double().numpy()
+            key = "%s/%s" % (name, pname)
+            g["gnorm:" + key] = np.float64(np.linalg.norm(gr))
+            g["gsample:" + key] = gr[MT.sample_idx(gr.size)]
+            n_params += 1
+    np.savez_compressed(os.path.join(HERE, "g16_neus_train.npz"), **g)
+    meta_path = os.path.join(HERE, "meta.json")
+    meta = json.load(open(meta_path))
+    meta["n_param_tensors_neus_train_golden"] = n_params
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print("G16 loss", loss.item(), "param tensors", n_params)
+
+
 def main():
     meta_path = os.path.join(HERE, "meta.json")
     meta = json.load(open(meta_path))
@@ -86,4 +125,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--train" in sys.argv:
+        train()
+    else:
+        main()

@@ -67,7 +67,7 @@ def test_neus_render_matches_reference_golden():
     w = _report(out, g, "G13")
     assert out["weights"].shape[1] == 64 + 64 + 32
     _check(w)
-    assert rel_l2(out["color_fine"].cpu().numpy(), g["color_fine"]) <= 1e-4
+    assert rel_l2(out["color_fine"].detach().cpu().numpy(), g["color_fine"]) <= 1e-4
     assert np.array_equal(out["inside_sphere"].cpu().numpy(), g["inside_sphere"])
 
 
@@ -120,13 +120,11 @@ def test_up_sample_and_merge_kernels_vs_oracle():
     assert torch.equal(gz.cpu(), zc) and torch.equal(gs.cpu(), sc)
 
 
-def test_neus_refuses_cpu_tensors_and_perturb():
+def test_neus_refuses_cpu_tensors_and_takes_empty_batches():
     r = _renderer(_stage1())
     g = golden("g13_neus.npz")
     with pytest.raises(Exception):
         r.render(t(g["rays_o"]), t(g["rays_d"]), t(g["near"]), t(g["far"]), perturb_overwrite=0)
-    with pytest.raises(NotImplementedError):
-        r.render(t(g["rays_o"]).cuda(), t(g["rays_d"]).cuda(), t(g["near"]).cuda(), t(g["far"]).cuda(), perturb_overwrite=1)
     out = r.render(t(g["rays_o"])[:0].cuda(), t(g["rays_d"])[:0].cuda(), t(g["near"])[:0].cuda(), t(g["far"])[:0].cuda(), perturb_overwrite=0)
     assert out["color_fine"].shape == (0, 3)
 

@@ -589,3 +589,70 @@ def test_nerf_backward_vs_autograd():
         ((a2 * ua.cuda()).sum() * ("a" in heads) + (r2 * ur.cuda()).sum() * ("r" in heads)).backward()
         w = _compare_param_grads(net, sd, 2e-4, "nerf n=%d %s" % (n, heads))
         print("nerf backward n=%d heads=%s worst rel-L2 %.2e (%s)" % (n, heads, w, getattr(_compare_param_grads, "last", "")))
+
+
+def _stage1_nets():
+    from iron_amd.fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    torch.manual_seed(0)
+    return {
+        "sdf_network": SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                                  geometric_init=True, weight_norm=True),
+        "color_network": RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=8, skip_in=[4],
+                                          weight_norm=True, multires=10, multires_view=4, squeeze_out=True),
+        "nerf": NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True),
+        "deviation_network": SingleVarianceNetwork(0.3),
+    }
+
+
+def test_g16_neus_training_render_matches_reference_gradients():
+    """NeuSRenderer.render under autograd + loss.backward() (render_volume.py:160-200: colour, eikonal statistic, weight_sum) vs
+    the REAL reference: gradient norm and sampled entries of all 79 parameter tensors of the four stage-1 networks (G16)."""
+    from iron_amd.renderer import NeuSRenderer
+    g, g13 = golden("g16_neus_train.npz"), golden("g13_neus.npz")
+    nets = {k: v.cuda() for k, v in _stage1_nets().items()}
+    r = NeuSRenderer(nets["nerf"], nets["sdf_network"], nets["deviation_network"], nets["color_network"], n_samples=64, n_importance=64,
+                     n_outside=32, up_sample_steps=4, perturb=0.0)
+    out = r.render(t(g13["rays_o"]).cuda(), t(g13["rays_d"]).cuda(), t(g13["near"]).cuda(), t(g13["far"]).cuda(), perturb_overwrite=0,
+                   background_rgb=None, cos_anneal_ratio=0.3)
+    assert out["color_fine"].requires_grad and out["gradient_error"].requires_grad and out["s_val"].requires_grad
+    assert np.abs(out["color_fine"].detach().cpu().numpy() - g["color_fine"]).max() <= 1e-4
+    loss = (out["color_fine"] * t(g["loss_wc"]).cuda()).sum() + 0.1 * out["gradient_error"] + (out["weight_sum"] * t(g["loss_ww"]).cuda()).sum()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    n, worst_n, worst_s, bad = 0, 0.0, 0.0, []
+    for name in sorted(nets):
+        for pname, p in nets[name].named_parameters():
+            key = "%s/%s" % (name, pname)
+            assert p.grad is not None, key
+            gr = p.grad.reshape(-1).double().cpu().numpy()
+            ref_n = float(g["gnorm:" + key])
+            en = abs(np.linalg.norm(gr) - ref_n) / max(ref_n, 1e-12)
+            ref_s = g["gsample:" + key]
+            idx = np.concatenate([np.arange(min(16, gr.size)), np.linspace(0, gr.size - 1, 32).astype(np.int64)])
+            es = float(np.abs(gr[idx] - ref_s).max() / max(np.abs(ref_s).max(), 1e-12))
+            worst_n, worst_s = max(worst_n, en), max(worst_s, es)
+            if en > 2e-3 or es > 5e-3:
+                bad.append((key, en, es))
+            n += 1
+    print("G16: %d parameter tensors, worst |norm| error %.2e, worst sampled-entry error %.2e (of max)" % (n, worst_n, worst_s))
+    assert not bad, bad
+    assert n == golden_meta()["n_param_tensors_neus_train_golden"]
+
+
+def test_neus_render_stratified_jitter_and_inference_mode():
+    """perturb > 0 (renderer.py:369-378) runs and stays a valid placement; under no_grad nothing is attached."""
+    from iron_amd.renderer import NeuSRenderer
+    g13 = golden("g13_neus.npz")
+    nets = {k: v.cuda() for k, v in _stage1_nets().items()}
+    r = NeuSRenderer(nets["nerf"], nets["sdf_network"], nets["deviation_network"], nets["color_network"], n_samples=64, n_importance=64,
+                     n_outside=32, up_sample_steps=4, perturb=1.0)
+    args = [t(g13[k]).cuda() for k in ("rays_o", "rays_d", "near", "far")]
+    torch.manual_seed(3)
+    a = r.render(*args, cos_anneal_ratio=0.5)
+    b = r.render(*args, cos_anneal_ratio=0.5)
+    assert a["color_fine"].requires_grad and a["weights"].shape == (96, 160)
+    assert float((a["color_fine"] - b["color_fine"]).abs().max()) > 0.0  # two different jitters
+    assert float(a["weight_sum"].max()) <= 1.0 + 1e-4 and bool(torch.isfinite(a["color_fine"]).all())
+    with torch.no_grad():
+        c = r.render(*args, perturb_overwrite=0, cos_anneal_ratio=0.5)
+    assert not c["color_fine"].requires_grad and not c["gradient_error"].requires_grad

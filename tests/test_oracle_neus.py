@@ -57,3 +57,38 @@ def test_g13_neus_render():
         assert tuple(out[k].shape) == g[k].shape, k
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=2e-5, atol=2e-6, err_msg=k)
     assert out["weights"].shape[1] == 64 + 64 + 32
+
+
+def test_g16_neus_training_gradients():
+    """render under autograd (render_volume.py:160-200): the oracle's render_train + torch.autograd vs the real reference's
+    gradients of all 79 parameter tensors of the four stage-1 networks."""
+    from oracle import train_ref as T
+    g = golden("g16_neus_train.npz")
+    g13 = golden("g13_neus.npz")
+    nets = _stage1()
+    sd = {k: T.leaf_state(cpu_sd(nets[k])) for k in ("sdf_network", "color_network", "nerf")}
+    var = nets["deviation_network"].variance.detach().clone().requires_grad_(True)
+    sc = N.NeusScene(sd["sdf_network"], R.SDFSpec(), sd["color_network"], sd["nerf"], var)
+    torch.set_num_threads(8)
+    out = N.render_train(sc, t(g13["rays_o"]), t(g13["rays_d"]), t(g13["near"]), t(g13["far"]), background_rgb=None, cos_anneal_ratio=0.3)
+    np.testing.assert_allclose(out["color_fine"].detach().numpy(), g["color_fine"], rtol=2e-5, atol=2e-6)
+    loss = (out["color_fine"] * t(g["loss_wc"])).sum() + 0.1 * out["gradient_error"] + (out["weight_sum"] * t(g["loss_ww"])).sum()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    n = 0
+    grads = {("deviation_network", "variance"): var.grad}
+    for name in sd:
+        for pname, p in sd[name].items():
+            if p.is_floating_point():
+                grads[(name, pname)] = p.grad
+    for (name, pname), gr in grads.items():
+        key = "%s/%s" % (name, pname)
+        assert gr is not None, key
+        gr = gr.reshape(-1).double().numpy()
+        ref_n = float(g["gnorm:" + key])
+        assert abs(np.linalg.norm(gr) - ref_n) <= 5e-4 * max(ref_n, 1e-12), (key, np.linalg.norm(gr), ref_n)
+        idx = np.concatenate([np.arange(min(16, gr.size)), np.linspace(0, gr.size - 1, 32).astype(np.int64)])
+        ref_s = g["gsample:" + key]
+        np.testing.assert_allclose(gr[idx], ref_s, rtol=5e-3, atol=5e-5 * max(np.abs(ref_s).max(), 1e-12), err_msg=key)
+        n += 1
+    assert n == golden_meta()["n_param_tensors_neus_train_golden"]

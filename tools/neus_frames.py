@@ -45,6 +45,7 @@ def run(rays: int = 40000, batches=(4096,), repeats: int = 1):
     o, d, near, far = o.cuda(), d.cuda(), near.cuda(), far.cuda()
     out = []
     for b in a.batches:
+        @torch.no_grad()
         def frame():
             for s in range(0, a.rays, b):
                 r.render(o[s:s + b], d[s:s + b], near[s:s + b], far[s:s + b], perturb_overwrite=0, cos_anneal_ratio=1.0)
