@@ -115,6 +115,15 @@ int iron_composite_colocated_backward(float light, const float* distance, const 
                                       const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
                                       const iron_composite_grads_in* upstream, const iron_composite_grads_out* out, void* stream);
 
+/* Backward of iron_coloc_head (SmoothDielectric / ThinDielectric / SmoothConductorCoLoc / RoughConductorCoLoc renderers,
+ * models/renderer_ggx.py:149-395; same `kind`, eta, k).  Upstream d_diffuse_rgb / d_specular_rgb / d_rgb [n,3], each nullable;
+ * outputs as iron_ggx_colocated_backward (d_roughness is non-zero for kind 3 only). */
+int iron_coloc_head_backward(int32_t kind, float light, float eta, float k, const float* distance, const float* normal,
+                             const float* viewdir, const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                             int64_t n, const float* d_diffuse_rgb, const float* d_specular_rgb, const float* d_rgb, float* d_light,
+                             float* d_distance, float* d_normal, float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo,
+                             float* d_roughness, void* stream);
+
 /* NeRF (models/fields.py:243-327, use_viewdirs=True): D ReLU layers of width W on PE(input_pts), `skip` = the layer after
  * whose activation the encoded input is concatenated IN FRONT (fields.py:309-310; -1: none), then alpha (1), feature (W), one
  * view layer on cat[feature, PE(views)] and rgb (3).  layers = the D point layers followed by alpha, feature, view, rgb; plain

@@ -169,6 +169,7 @@ TRAIN_SYMBOLS = {
     "iron_ggx_colocated_backward": (C.c_int, [_F] + [_P] * 8 + [_I64] + [_P] * 10 + [_P]),
     "iron_composite_colocated_backward": (C.c_int, [_F, _P, _P, _P, C.POINTER(iron_composite_params), _P, _P, _I64,
                                                     C.POINTER(iron_composite_grads_in), C.POINTER(iron_composite_grads_out), _P]),
+    "iron_coloc_head_backward": (C.c_int, [_I32, _F, _F, _F] + [_P] * 6 + [_I64] + [_P] * 10 + [_P]),
     "iron_nerf_backward_workspace_bytes": (_SZ, [C.POINTER(iron_nerf_train_desc), _I64]),
     "iron_nerf_backward": (C.c_int, [C.POINTER(iron_nerf_train_desc), _P, _P, _I64, _P, _P, _P, _SZ, _P]),
     "iron_neus_composite_backward": (C.c_int, [C.POINTER(iron_neus_composite_args), C.POINTER(iron_neus_composite_grads), _P]),

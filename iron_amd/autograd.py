@@ -294,6 +294,61 @@ class CompositeFn(torch.autograd.Function):
                 d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(m.reshape(s) for m, s in zip(d_maps, ctx.shapes[5:]))
 
 
+class ColocHeadFn(torch.autograd.Function):
+    """(diffuse_rgb, specular_rgb, rgb) of the four simple co-located heads (models/renderer_ggx.py:149-395)."""
+
+    @staticmethod
+    def forward(ctx, head, light, distance, normal, viewdir, kd, ks, alpha):
+        ctx.set_materialize_grads(False)
+        ctx.head = head
+        ctx.light_shape = light.shape if torch.is_tensor(light) else None
+        ctx.light_value = float(light)
+        with torch.no_grad():
+            out = head._forward_values(ctx.light_value, distance, normal, viewdir, kd, ks, alpha)
+        ctx.has_alpha = alpha is not None
+        ctx.shapes = (distance.shape, normal.shape, viewdir.shape, kd.shape, ks.shape, None if alpha is None else alpha.shape)
+        ctx.save_for_backward(distance.detach(), normal.detach(), viewdir.detach(), kd.detach(), ks.detach(),
+                              *([alpha.detach()] if alpha is not None else []))
+        return out["diffuse_rgb"], out["specular_rgb"], out["rgb"]
+
+    @staticmethod
+    def backward(ctx, g_diff, g_spec, g_rgb):
+        saved = list(ctx.saved_tensors)
+        dist, nrm, vd, kd, ks = saved[:5]
+        alpha = saved[5] if ctx.has_alpha else None
+        head = ctx.head
+        nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
+        n = nrm.shape[0]
+        dev = nrm.device
+        sh = list(ctx.shapes[1][:-1])
+        dist = _lib.require_cuda_f32(dist, "distance").reshape(-1)
+        vd = _lib.require_cuda_f32(vd, "viewdir").reshape(-1, 3)
+        kd_f = _lib.require_cuda_f32(kd.expand(sh + [3]), "diffuse_albedo").reshape(-1, 3)
+        ks_f = _lib.require_cuda_f32(ks.expand(sh + [3]), "specular_albedo").reshape(-1, 3)
+        al = _lib.require_cuda_f32(alpha, "alpha").reshape(-1) if (alpha is not None and head.KIND == 3) else None
+        ups = [_opt(g, (-1, 3)) for g in (g_diff, g_spec, g_rgb)]
+        with torch.cuda.device(dev):
+            d_light = torch.zeros(1, dtype=torch.float32, device=dev)
+            d_dist = torch.empty_like(dist)
+            d_nrm, d_vd, d_kd, d_ks = (torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(4))
+            d_al = torch.empty_like(al) if al is not None else None
+            _lib.check_train(_lib.load_train().iron_coloc_head_backward(
+                head.KIND, ctx.light_value, float(head.eta), float(head.k), dist.data_ptr(), nrm.data_ptr(), vd.data_ptr(), kd_f.data_ptr(),
+                ks_f.data_ptr(), _lib.ptr(al), n, _lib.ptr(ups[0]), _lib.ptr(ups[1]), _lib.ptr(ups[2]), d_light.data_ptr(), d_dist.data_ptr(),
+                d_nrm.data_ptr(), d_vd.data_ptr(), d_kd.data_ptr(), d_ks.data_ptr(), _lib.ptr(d_al), _lib.stream_ptr(dev)))
+        s_dist, s_nrm, s_vd, s_kd, s_ks, s_al = ctx.shapes
+
+        def unvec(g, shape):
+            g = g.reshape(sh + [3])
+            return (g.sum(dim=-1, keepdim=True) if shape[-1] == 1 else g).reshape(shape)
+
+        d_alpha = None
+        if ctx.has_alpha:
+            d_alpha = d_al.reshape(s_al) if d_al is not None else torch.zeros(s_al, dtype=torch.float32, device=dev)
+        return (None, d_light.reshape(ctx.light_shape) if ctx.light_shape is not None else None, d_dist.reshape(s_dist), d_nrm.reshape(s_nrm),
+                d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks), d_alpha)
+
+
 class NeRFFn(torch.autograd.Function):
     """(alpha [n,1], rgb [n,3]) = NeRF(input_pts [n,4], input_views [n,3]); differentiable w.r.t. the parameters (the reference
     feeds sample positions computed without grad, renderer.py:163-172, so the inputs get none)."""

@@ -770,6 +770,82 @@ __global__ void k_composite_back(CompBackArgs a) {
     }
 }
 
+// ---- the four simple co-located heads (models/renderer_ggx.py:149-395; kinds as iron_coloc_head) --------------------------------
+struct HeadBackArgs {
+    const float *dist, *nrm, *view, *kd, *ks, *rough, *g_diff, *g_spec, *g_rgb;
+    float *d_light, *d_dist, *d_nrm, *d_view, *d_kd, *d_ks, *d_rough;
+    float light, eta, k;
+    int kind, n;
+};
+
+__global__ void k_coloc_head_back(HeadBackArgs a) {
+    typedef Dual<3> D3d;  // (cos, roughness, distance)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float light_acc = 0.0f;
+    if (p < a.n) {
+        const float* nn = a.nrm + 3 * (size_t)p;
+        const float* vv = a.view + 3 * (size_t)p;
+        const float raw_dot = (vv[0] * nn[0] + vv[1] * nn[1]) + vv[2] * nn[2];
+        const float cdot = fminf(fmaxf(raw_dot, 0.00001f), 0.99999f);
+        const bool dot_live = raw_dot >= 0.00001f && raw_dot <= 0.99999f;
+        const float r_in = a.rough ? a.rough[p] : 1.0f;
+        const bool rough_live = a.kind == 3 && r_in >= 0.0001f;
+        const D3d c = dvar<3>(cdot, 0), al = dvar<3>(fmaxf(r_in, 0.0001f), 1), ds = dvar<3>(a.dist[p], 2);
+        const D3d one = dc<3>(1.0f);
+        const D3d U = one / (ds * ds + dc<3>(1e-10f));
+        D3d S;  // specular per unit light and specular albedo
+        if (a.kind == 0) {
+            S = U * dc<3>(0.04f);
+        } else if (a.kind == 1) {
+            S = U * dc<3>((float)(0.04 + 0.96 * 0.96 * 0.04 / (1.0 - 0.04 * 0.04)));
+        } else {
+            const D3d c2 = c * c, s2 = one - c2, s4 = s2 * s2;
+            const D3d me = dc<3>(a.eta), mk = dc<3>(a.k);
+            const D3d temp1 = me * me - mk * mk - s2;
+            const D3d a2pb2 = dsqrt(temp1 * temp1 + dc<3>(4.0f) * mk * mk * me * me);
+            const D3d aa = dsqrt(dc<3>(0.5f) * (a2pb2 + temp1));
+            const D3d term1 = a2pb2 + c2, term2 = dc<3>(2.0f) * aa * c;
+            const D3d rs2 = (term1 - term2) / (term1 + term2);
+            const D3d term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+            const D3d rp2 = rs2 * (term3 - term4) / (term3 + term4);
+            S = U * dc<3>(0.5f) * (rp2 + rs2);
+            if (a.kind == 3) {
+                const D3d a2 = al * al;
+                const D3d root = c2 + s2 / (a2 + dc<3>(1e-10f));
+                const D3d Dn = one / (dc<3>(3.14159274101257324219f) * a2 * root * root + dc<3>(1e-10f));
+                const D3d rt = al * (dsqrt(s2) / (c + dc<3>(1e-10f)));
+                const D3d g1 = dc<3>(2.0f) / (one + dsqrt(rt * rt + one));
+                S = S * Dn * (g1 * g1) / (dc<3>(4.0f) * c + dc<3>(1e-10f));
+            }
+        }
+        const D3d Df = U * dc<3>(0.0001f);  // diffuse per unit light and diffuse albedo
+        float As = 0.f, Ad = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t q = 3 * (size_t)p + k;
+            const float g_r = a.g_rgb ? a.g_rgb[q] : 0.f;
+            const float gd = (a.g_diff ? a.g_diff[q] : 0.f) + g_r, gs = (a.g_spec ? a.g_spec[q] : 0.f) + g_r;
+            if (a.d_kd) a.d_kd[q] = gd * a.light * Df.v;
+            if (a.d_ks) a.d_ks[q] = gs * a.light * S.v;
+            Ad += gd * a.kd[q];
+            As += gs * a.ks[q];
+        }
+        light_acc = As * S.v + Ad * Df.v;
+        const float dcos = dot_live ? a.light * (As * S.d[0] + Ad * Df.d[0]) : 0.f;
+        if (a.d_rough) a.d_rough[p] = rough_live ? a.light * (As * S.d[1]) : 0.f;
+        if (a.d_dist) a.d_dist[p] = a.light * (As * S.d[2] + Ad * Df.d[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.d_nrm) a.d_nrm[3 * (size_t)p + k] = dcos * vv[k];
+            if (a.d_view) a.d_view[3 * (size_t)p + k] = dcos * nn[k];
+        }
+    }
+    if (a.d_light) {
+        for (int o = 32; o > 0; o >>= 1) light_acc += __shfl_xor(light_acc, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.d_light, light_acc);
+    }
+}
+
 // ---- NeRF background field (models/fields.py:243-327), parameter gradients --------------------------------------------------------
 // PE of a `dims`-wide input: [x, sin(2^0 x), cos(2^0 x), ...], each block `dims` wide
 __device__ __forceinline__ float pe_val(const float* x, int c, int dims) {
@@ -1066,6 +1142,27 @@ __global__ void k_neus_composite_back(NeusBackArgs a) {
 }  // namespace iron_train
 
 using namespace iron_train;
+
+extern "C" int iron_coloc_head_backward(int32_t kind, float light, float eta, float k, const float* distance, const float* normal,
+                                        const float* viewdir, const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
+                                        int64_t n, const float* d_diffuse_rgb, const float* d_specular_rgb, const float* d_rgb, float* d_light,
+                                        float* d_distance, float* d_normal, float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo,
+                                        float* d_roughness, void* stream) {
+    if (n < 0 || kind < 0 || kind > 3) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_light) TR_HIP(hipMemsetAsync(d_light, 0, sizeof(float), st));
+    if (n == 0) return IRON_OK;
+    if (!distance || !normal || !viewdir || !diffuse_albedo || !specular_albedo || (kind == 3 && !roughness)) return IRON_ERR_BAD_ARG;
+    HeadBackArgs a;
+    a.dist = distance; a.nrm = normal; a.view = viewdir; a.kd = diffuse_albedo; a.ks = specular_albedo; a.rough = kind == 3 ? roughness : nullptr;
+    a.g_diff = d_diffuse_rgb; a.g_spec = d_specular_rgb; a.g_rgb = d_rgb;
+    a.d_light = d_light; a.d_dist = d_distance; a.d_nrm = d_normal; a.d_view = d_viewdir; a.d_kd = d_diffuse_albedo; a.d_ks = d_specular_albedo;
+    a.d_rough = d_roughness;
+    a.light = light; a.eta = eta; a.k = k; a.kind = kind; a.n = (int)n;
+    hipLaunchKernelGGL(k_coloc_head_back, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
 
 extern "C" size_t iron_nerf_backward_workspace_bytes(const iron_nerf_train_desc* desc, int64_t n) {
     NerfPlan P;

@@ -176,8 +176,13 @@ class _ColocHead(nn.Module):
         self.eta, self.k = 0.0, 0.0
 
     def forward(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha=None):
-        from .autograd import refuse_grad
-        refuse_grad(type(self).__name__ + ".forward", light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha)
+        from .autograd import ColocHeadFn, any_requires_grad
+        if any_requires_grad(light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha):
+            d, s, rgb = ColocHeadFn.apply(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha)
+            return {"diffuse_rgb": d, "specular_rgb": s, "rgb": rgb}
+        return self._forward_values(float(light), distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha)
+
+    def _forward_values(self, light, distance, normal, viewdir, diffuse_albedo, specular_albedo, alpha=None):
         nrm = _lib.require_cuda_f32(normal.detach(), "normal")
         sh = list(nrm.shape[:-1])
         nrm = nrm.reshape(-1, 3)

@@ -656,3 +656,37 @@ def test_neus_render_stratified_jitter_and_inference_mode():
     with torch.no_grad():
         c = r.render(*args, perturb_overwrite=0, cos_anneal_ratio=0.5)
     assert not c["color_fine"].requires_grad and not c["gradient_error"].requires_grad
+
+
+@pytest.mark.parametrize("kind", ["smooth_dielectric", "thin_dielectric", "smooth_conductor", "rough_conductor"])
+def test_simple_head_backward_vs_autograd(kind):
+    """SmoothDielectric / ThinDielectric / SmoothConductorCoLoc / RoughConductorCoLoc (renderer_ggx.py:149-395) under autograd."""
+    from iron_amd import renderer_ggx as G
+    from oracle import iron_ref as R
+    cls = {"smooth_dielectric": G.SmoothDielectricRenderer, "thin_dielectric": G.ThinDielectricRenderer,
+           "smooth_conductor": G.SmoothConductorCoLocRenderer, "rough_conductor": G.RoughConductorCoLocRenderer}[kind]
+    head = cls(use_cuda=True) if kind.endswith("dielectric") else cls(ior_path="./resource/ior", use_cuda=True)
+    ofn = getattr(R, kind)
+    gen = torch.Generator().manual_seed(51)
+    n = 2051
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    vd = torch.nn.functional.normalize(nrm + 0.9 * torch.randn(n, 3, generator=gen), dim=-1)
+    ins = {"light": torch.tensor(21.0), "distance": torch.rand(n, 1, generator=gen) * 2 + 0.5, "normal": nrm, "viewdir": vd,
+           "kd": torch.rand(n, 3, generator=gen), "ks": torch.rand(n, 3, generator=gen) * 0.5, "alpha": torch.rand(n, 1, generator=gen) * 0.6 + 0.01}
+    ups = [torch.randn(n, 3, generator=gen) for _ in range(3)]
+
+    def run(dev, fn):
+        v = {k: x.clone().to(dev).requires_grad_(True) for k, x in ins.items()}
+        out = fn(v)
+        sum((out[k] * u.to(dev)).sum() for k, u in zip(("diffuse_rgb", "specular_rgb", "rgb"), ups)).backward()
+        return {k: (x.grad.detach().cpu().numpy() if x.grad is not None else np.zeros(tuple(x.shape), np.float32)) for k, x in v.items()}
+
+    ref = run("cpu", lambda v: ofn(v["light"], v["distance"], v["normal"], v["viewdir"], v["kd"], v["ks"], v["alpha"]))
+    got = run("cuda", lambda v: head(v["light"], v["distance"], v["normal"], v["viewdir"], v["kd"], v["ks"], v["alpha"]))
+    for k in ins:
+        if float(np.abs(ref[k]).max()) == 0.0:
+            assert float(np.abs(got[k]).max()) == 0.0, k
+            continue
+        r = _rel(got[k], ref[k])
+        print("%s d/d%s rel-L2 %.2e" % (kind, k, r))
+        assert r <= 1e-4, (kind, k, r)
