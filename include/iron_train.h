@@ -88,8 +88,9 @@ int iron_ggx_colocated_backward(float light, const float* distance, const float*
                                 const float* d_specular_rgb, const float* d_rgb, float* d_light, float* d_distance, float* d_normal,
                                 float* d_viewdir, float* d_diffuse_albedo, float* d_specular_albedo, float* d_roughness, void* stream);
 
-/* Backward of CompositeRenderer.forward (models/renderer_ggx.py:781-858), point-light branch (p->env_light must be NULL:
- * IRON_ERR_UNSUPPORTED otherwise).  Upstream: d_rgb (the reference returns the SAME tensor as "rgb" and "diffuse_rgb"; pass
+/* Backward of CompositeRenderer.forward (models/renderer_ggx.py:781-858), both branches (p->env_light != NULL: use_env_light,
+ * intensity = clamp(env_light, 1e-6, 20); d_light / d_distance are then zero and d_env_light receives the gradient, including
+ * that of the returned "env_light" key, d_env_light_out).  Upstream: d_rgb (the reference returns the SAME tensor as "rgb" and "diffuse_rgb"; pass
  * the sum of both keys' gradients), d_specular_rgb, d_metallic_rgb, d_dielectric_rgb, each [n,3] or NULL.  Outputs, each
  * nullable: d_light [1]; d_distance, the four scalar maps [n]; d_normal, d_viewdir, the two albedos [n,3].  Clamped inputs
  * carry gradient on the closed clamp interval, the diffuse tables none. */
@@ -98,6 +99,7 @@ typedef struct iron_composite_grads_in {
     const float* d_specular_rgb;
     const float* d_metallic_rgb;
     const float* d_dielectric_rgb;
+    const float* d_env_light_out; /* [n] or NULL (env-light branch: upstream of the returned clamped env light) */
 } iron_composite_grads_in;
 typedef struct iron_composite_grads_out {
     float* d_light;
@@ -110,6 +112,7 @@ typedef struct iron_composite_grads_out {
     float* d_metallic_eta;
     float* d_metallic_k;
     float* d_dielectric_eta;
+    float* d_env_light; /* [n] or NULL */
 } iron_composite_grads_out;
 int iron_composite_colocated_backward(float light, const float* distance, const float* normal, const float* viewdir,
                                       const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,

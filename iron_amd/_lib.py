@@ -142,12 +142,12 @@ class iron_render_train_desc(C.Structure):
 
 
 class iron_composite_grads_in(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("d_rgb", "d_specular_rgb", "d_metallic_rgb", "d_dielectric_rgb")]
+    _fields_ = [(k, C.c_void_p) for k in ("d_rgb", "d_specular_rgb", "d_metallic_rgb", "d_dielectric_rgb", "d_env_light_out")]
 
 
 class iron_composite_grads_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("d_light", "d_distance", "d_normal", "d_viewdir", "d_diffuse_albedo", "d_specular_albedo",
-                                          "d_specular_roughness", "d_metallic_eta", "d_metallic_k", "d_dielectric_eta")]
+                                          "d_specular_roughness", "d_metallic_eta", "d_metallic_k", "d_dielectric_eta", "d_env_light")]
 
 
 class iron_nerf_train_desc(C.Structure):

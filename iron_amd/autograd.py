@@ -226,33 +226,40 @@ class GGXColocatedFn(torch.autograd.Function):
 
 
 class CompositeFn(torch.autograd.Function):
-    """(rgb, specular_rgb, metallic_rgb, dielectric_rgb) = CompositeRenderer(light, distance, normal, viewdir, kd, ks, roughness,
-    metallic_eta, metallic_k, dielectric_eta), point-light branch (models/renderer_ggx.py:781-858).  "diffuse_rgb" is the same
-    tensor as "rgb" in the reference, so the caller maps both keys to the first output."""
+    """(rgb, specular_rgb, metallic_rgb, dielectric_rgb, env_light) = CompositeRenderer(light, distance, normal, viewdir, kd, ks,
+    roughness, metallic_eta, metallic_k, dielectric_eta, env_light) (models/renderer_ggx.py:781-858).  env_light None = the
+    point-light branch (the last output is then an empty placeholder).  "diffuse_rgb" is the same tensor as "rgb" in the
+    reference, so the caller maps both keys to the first output."""
 
     NAMES = ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta", "metallic_k", "dielectric_eta")
 
     @staticmethod
-    def forward(ctx, renderer, light, distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta):
+    def forward(ctx, renderer, light, distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta, env_light):
         ctx.set_materialize_grads(False)
         ctx.renderer = renderer
         ctx.light_shape = light.shape if torch.is_tensor(light) else None
         ctx.light_value = float(light)
+        ctx.use_env = env_light is not None
         params = dict(zip(CompositeFn.NAMES, (kd, ks, rough, m_eta, m_k, d_eta)))
         params["metallic"] = params["dielectric"] = rough  # read and ignored by the reference (:829-831)
+        if ctx.use_env:
+            params["env_light"] = env_light
         with torch.no_grad():
-            out = renderer._forward_values(ctx.light_value, distance, normal, viewdir, params, False)
-        ctx.shapes = tuple(t.shape for t in (distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta))
-        ctx.save_for_backward(*(t.detach() for t in (distance, normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta)))
-        return out["rgb"], out["specular_rgb"], out["metallic_rgb"], out["dielectric_rgb"]
+            out = renderer._forward_values(ctx.light_value, distance, normal, viewdir, params, ctx.use_env)
+        tensors = [normal, viewdir, kd, ks, rough, m_eta, m_k, d_eta, env_light if ctx.use_env else distance]
+        ctx.shapes = tuple(t.shape for t in tensors)
+        ctx.dist_shape = distance.shape if torch.is_tensor(distance) else None
+        ctx.save_for_backward(*(t.detach() for t in tensors))
+        env_out = out["env_light"] if ctx.use_env else normal.new_zeros(0)
+        return out["rgb"], out["specular_rgb"], out["metallic_rgb"], out["dielectric_rgb"], env_out
 
     @staticmethod
-    def backward(ctx, g_rgb, g_spec, g_met, g_die):
-        dist, nrm, vd, kd, ks, rough, m_eta, m_k, d_eta = ctx.saved_tensors
+    def backward(ctx, g_rgb, g_spec, g_met, g_die, g_env):
+        nrm, vd, kd, ks, rough, m_eta, m_k, d_eta, last = ctx.saved_tensors
         nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
         n = nrm.shape[0]
         dev = nrm.device
-        sh = list(ctx.shapes[1][:-1])
+        sh = list(ctx.shapes[0][:-1])
 
         def vec(t, name):
             t = _lib.require_cuda_f32(t, name)
@@ -261,37 +268,50 @@ class CompositeFn(torch.autograd.Function):
         def sca(t, name):
             return _lib.require_cuda_f32(t, name).reshape(-1)
 
-        dist, vd = sca(dist, "distance"), vec(vd, "viewdir")
+        vd = vec(vd, "viewdir")
         kd_f, ks_f = vec(kd, "diffuse_albedo"), vec(ks, "specular_albedo")
         maps = [sca(t, k) for t, k in zip((rough, m_eta, m_k, d_eta), CompositeFn.NAMES[2:])]
+        last = sca(last, "env_light" if ctx.use_env else "distance")
         t1, t2 = ctx.renderer._tables_on(dev)
         ups = [_opt(g, (-1, 3)) for g in (g_rgb, g_spec, g_met, g_die)]
+        g_env = _opt(g_env, (-1,)) if ctx.use_env else None
         lib = _lib.load_train()
         with torch.cuda.device(dev):
             p = _lib.iron_composite_params()
             p.diffuse_albedo, p.specular_albedo, p.specular_roughness = kd_f.data_ptr(), ks_f.data_ptr(), maps[0].data_ptr()
-            p.metallic_eta, p.metallic_k, p.dielectric_eta, p.env_light = maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), None
+            p.metallic_eta, p.metallic_k, p.dielectric_eta = maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr()
+            p.env_light = last.data_ptr() if ctx.use_env else None
             gi = _lib.iron_composite_grads_in()
             gi.d_rgb, gi.d_specular_rgb, gi.d_metallic_rgb, gi.d_dielectric_rgb = (_lib.ptr(u) for u in ups)
+            gi.d_env_light_out = _lib.ptr(g_env)
             d_light = torch.zeros(1, dtype=torch.float32, device=dev)
-            d_dist = torch.empty_like(dist)
+            d_last = torch.empty_like(last)
             d_nrm, d_vd, d_kd, d_ks = (torch.empty((n, 3), dtype=torch.float32, device=dev) for _ in range(4))
             d_maps = [torch.empty_like(m) for m in maps]
             go = _lib.iron_composite_grads_out()
-            go.d_light, go.d_distance, go.d_normal, go.d_viewdir = d_light.data_ptr(), d_dist.data_ptr(), d_nrm.data_ptr(), d_vd.data_ptr()
+            go.d_light, go.d_normal, go.d_viewdir = d_light.data_ptr(), d_nrm.data_ptr(), d_vd.data_ptr()
+            go.d_distance = None if ctx.use_env else d_last.data_ptr()
+            go.d_env_light = d_last.data_ptr() if ctx.use_env else None
             go.d_diffuse_albedo, go.d_specular_albedo = d_kd.data_ptr(), d_ks.data_ptr()
             go.d_specular_roughness, go.d_metallic_eta, go.d_metallic_k, go.d_dielectric_eta = (m.data_ptr() for m in d_maps)
-            _lib.check_train(lib.iron_composite_colocated_backward(ctx.light_value, dist.data_ptr(), nrm.data_ptr(), vd.data_ptr(), C.byref(p),
-                                                                   t1.data_ptr(), t2.data_ptr(), n, C.byref(gi), C.byref(go),
+            _lib.check_train(lib.iron_composite_colocated_backward(ctx.light_value, None if ctx.use_env else last.data_ptr(), nrm.data_ptr(),
+                                                                   vd.data_ptr(), C.byref(p), t1.data_ptr(), t2.data_ptr(), n, C.byref(gi), C.byref(go),
                                                                    _lib.stream_ptr(dev)))
-        s_dist, s_nrm, s_vd, s_kd, s_ks = ctx.shapes[:5]
+        s_nrm, s_vd, s_kd, s_ks = ctx.shapes[:4]
 
         def unvec(g, shape):
             g = g.reshape(sh + [3])
             return (g.sum(dim=-1, keepdim=True) if shape[-1] == 1 else g).reshape(shape)
 
-        return (None, d_light.reshape(ctx.light_shape) if ctx.light_shape is not None else None, d_dist.reshape(s_dist), d_nrm.reshape(s_nrm),
-                d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(m.reshape(s) for m, s in zip(d_maps, ctx.shapes[5:]))
+        d_light_out = d_light.reshape(ctx.light_shape) if (ctx.light_shape is not None and not ctx.use_env) else None
+        d_dist = None
+        if not ctx.use_env:
+            d_dist = d_last.reshape(ctx.shapes[8])
+        elif ctx.dist_shape is not None:
+            d_dist = torch.zeros(ctx.dist_shape, dtype=torch.float32, device=dev)
+        d_env = d_last.reshape(ctx.shapes[8]) if ctx.use_env else None
+        return (None, d_light_out, d_dist, d_nrm.reshape(s_nrm), d_vd.reshape(s_vd), unvec(d_kd, s_kd), unvec(d_ks, s_ks)) + tuple(
+            m.reshape(s) for m, s in zip(d_maps, ctx.shapes[4:8])) + (d_env,)
 
 
 class ColocHeadFn(torch.autograd.Function):

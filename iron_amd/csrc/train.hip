@@ -666,9 +666,9 @@ template <int N> __device__ __forceinline__ Dual<N> dsqrt(Dual<N> a) {
 }
 
 struct CompBackArgs {
-    const float *dist, *nrm, *view, *kd, *ks, *rough, *m_eta, *m_k, *d_eta, *tab_trans, *tab_diff;
-    const float *g_rgb, *g_spec, *g_met, *g_die;
-    float *d_light, *d_dist, *d_nrm, *d_view, *d_kd, *d_ks, *d_rough, *d_m_eta, *d_m_k, *d_d_eta;
+    const float *dist, *nrm, *view, *kd, *ks, *rough, *m_eta, *m_k, *d_eta, *env, *tab_trans, *tab_diff;
+    const float *g_rgb, *g_spec, *g_met, *g_die, *g_env;
+    float *d_light, *d_dist, *d_nrm, *d_view, *d_kd, *d_ks, *d_rough, *d_m_eta, *d_m_k, *d_d_eta, *d_env;
     float light;
     int n;
 };
@@ -688,7 +688,10 @@ __global__ void k_composite_back(CompBackArgs a) {
         const float de0 = fminf(fmaxf(de_in, 1.000001f), 1.999999f);
         const float me0 = fminf(fmaxf(me_in, 0.099999f), 4.999999f);
         const float mk0 = fminf(fmaxf(mk_in, 0.099999f), 9.999999f);
-        const bool live[6] = {dot_live, r_in >= 0.00001f, true, me_in >= 0.099999f && me_in <= 4.999999f,
+        const bool use_env = a.env != nullptr;  // intensity = clamp(env_light, 1e-6, 20) instead of light / (d^2 + 1e-10)
+        const float env_in = use_env ? a.env[p] : 0.0f;
+        const bool live[6] = {dot_live, r_in >= 0.00001f, use_env ? (env_in >= 0.000001f && env_in <= 20.0f) : true,
+                              me_in >= 0.099999f && me_in <= 4.999999f,
                               mk_in >= 0.099999f && mk_in <= 9.999999f, de_in >= 1.000001f && de_in <= 1.999999f};
         // piecewise-constant diffuse tables (alpha := max(rough, 1e-4) as CompositeRenderer.diffuse_reflection_ggx does)
         const float alpha_t = fmaxf(rough0, 0.0001f);
@@ -705,10 +708,16 @@ __global__ void k_composite_back(CompBackArgs a) {
         const float eta2 = (float)(1.48958738 * 1.48958738 + 1e-10);
         const float pi_eta2 = (float)(3.141592653589793 * 1.48958738 * 1.48958738);
 
-        const D6 c = dvar<6>(cdot, 0), rg = dvar<6>(rough0, 1), ds = dvar<6>(a.dist[p], 2), me = dvar<6>(me0, 3), mk = dvar<6>(mk0, 4),
-                 de = dvar<6>(de0, 5);
+        const D6 c = dvar<6>(cdot, 0), rg = dvar<6>(rough0, 1), me = dvar<6>(me0, 3), mk = dvar<6>(mk0, 4), de = dvar<6>(de0, 5);
         const D6 one = dc<6>(1.0f);
-        const D6 U = one / (ds * ds + dc<6>(1e-10f));
+        D6 U;  // intensity per unit `lightf`: variable 2 is the distance (point light) or the env-light value
+        if (use_env) {
+            U = dvar<6>(fminf(fmaxf(env_in, 0.000001f), 20.0f), 2);
+        } else {
+            const D6 ds = dvar<6>(a.dist[p], 2);
+            U = one / (ds * ds + dc<6>(1e-10f));
+        }
+        const float lightf = use_env ? 1.0f : a.light;
         const D6 c2 = c * c, s2 = one - c2;
         // GGX NDF with alpha := eta (the reference's quirk), Smith G1 with the roughness
         const D6 root = c2 + s2 / dc<6>(eta2);
@@ -745,16 +754,17 @@ __global__ void k_composite_back(CompBackArgs a) {
             const float gd = (a.g_die ? a.g_die[q] : 0.f) + g_s + g_r;
             const float ks_in = a.ks[q], kd_in = a.kd[q];
             const float ks = fmaxf(ks_in, 0.00001f), kd = fmaxf(kd_in, 0.00001f);
-            if (a.d_ks) a.d_ks[q] = ks_in >= 0.00001f ? a.light * (gm * M.v + gd * Dl.v) : 0.f;
-            if (a.d_kd) a.d_kd[q] = kd_in >= 0.00001f ? a.light * (g_r * Df.v) : 0.f;
+            if (a.d_ks) a.d_ks[q] = ks_in >= 0.00001f ? lightf * (gm * M.v + gd * Dl.v) : 0.f;
+            if (a.d_kd) a.d_kd[q] = kd_in >= 0.00001f ? lightf * (g_r * Df.v) : 0.f;
             Am += gm * ks; Ad += gd * ks; Af += g_r * kd;
         }
-        light_acc = (Am * M.v + Ad * Dl.v) + Af * Df.v;
+        light_acc = use_env ? 0.0f : (Am * M.v + Ad * Dl.v) + Af * Df.v;
         float dv[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dv[k] = live[k] ? a.light * ((Am * M.d[k] + Ad * Dl.d[k]) + Af * Df.d[k]) : 0.f;
+        for (int k = 0; k < 6; ++k) dv[k] = live[k] ? lightf * ((Am * M.d[k] + Ad * Dl.d[k]) + Af * Df.d[k]) : 0.f;
         if (a.d_rough) a.d_rough[p] = dv[1];
-        if (a.d_dist) a.d_dist[p] = dv[2];
+        if (a.d_dist) a.d_dist[p] = use_env ? 0.0f : dv[2];
+        if (a.d_env) a.d_env[p] = use_env ? dv[2] + ((a.g_env && live[2]) ? a.g_env[p] : 0.0f) : 0.0f;  // "env_light" output = the clamp itself
         if (a.d_m_eta) a.d_m_eta[p] = dv[3];
         if (a.d_m_k) a.d_m_k[p] = dv[4];
         if (a.d_d_eta) a.d_d_eta[p] = dv[5];
@@ -1200,20 +1210,20 @@ extern "C" int iron_composite_colocated_backward(float light, const float* dista
                                                  const iron_composite_params* p, const float* tab_trans, const float* tab_diff, int64_t n,
                                                  const iron_composite_grads_in* g, const iron_composite_grads_out* o, void* stream) {
     if (n < 0 || !p || !g || !o) return IRON_ERR_BAD_ARG;
-    if (p->env_light) return IRON_ERR_UNSUPPORTED;  // the env-light branch has no backward here
     hipStream_t st = (hipStream_t)stream;
     if (o->d_light) TR_HIP(hipMemsetAsync(o->d_light, 0, sizeof(float), st));
     if (n == 0) return IRON_OK;
-    if (!distance || !normal || !viewdir || !p->diffuse_albedo || !p->specular_albedo || !p->specular_roughness || !p->metallic_eta ||
+    if ((!distance && !p->env_light) || !normal || !viewdir || !p->diffuse_albedo || !p->specular_albedo || !p->specular_roughness || !p->metallic_eta ||
         !p->metallic_k || !p->dielectric_eta || !tab_trans || !tab_diff)
         return IRON_ERR_BAD_ARG;
     CompBackArgs a;
     a.dist = distance; a.nrm = normal; a.view = viewdir; a.kd = p->diffuse_albedo; a.ks = p->specular_albedo; a.rough = p->specular_roughness;
-    a.m_eta = p->metallic_eta; a.m_k = p->metallic_k; a.d_eta = p->dielectric_eta; a.tab_trans = tab_trans; a.tab_diff = tab_diff;
-    a.g_rgb = g->d_rgb; a.g_spec = g->d_specular_rgb; a.g_met = g->d_metallic_rgb; a.g_die = g->d_dielectric_rgb;
+    a.m_eta = p->metallic_eta; a.m_k = p->metallic_k; a.d_eta = p->dielectric_eta; a.env = p->env_light; a.tab_trans = tab_trans;
+    a.tab_diff = tab_diff;
+    a.g_rgb = g->d_rgb; a.g_spec = g->d_specular_rgb; a.g_met = g->d_metallic_rgb; a.g_die = g->d_dielectric_rgb; a.g_env = g->d_env_light_out;
     a.d_light = o->d_light; a.d_dist = o->d_distance; a.d_nrm = o->d_normal; a.d_view = o->d_viewdir; a.d_kd = o->d_diffuse_albedo;
     a.d_ks = o->d_specular_albedo; a.d_rough = o->d_specular_roughness; a.d_m_eta = o->d_metallic_eta; a.d_m_k = o->d_metallic_k;
-    a.d_d_eta = o->d_dielectric_eta;
+    a.d_d_eta = o->d_dielectric_eta; a.d_env = o->d_env_light;
     a.light = light; a.n = (int)n;
     hipLaunchKernelGGL(k_composite_back, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
     TR_HIP(hipGetLastError());

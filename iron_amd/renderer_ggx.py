@@ -116,16 +116,18 @@ class CompositeRenderer(nn.Module):
         [...,1] (+ metallic, dielectric, which the reference clamps and never uses; + env_light when use_env_light).
         Returns diffuse_rgb, specular_rgb, metallic_rgb, dielectric_rgb, rgb (+ env_light); as in the reference,
         "diffuse_rgb" IS "rgb" (the same tensor: :847-853 add the specular term in place).  Differentiable under grad mode on the
-        point-light branch (HIP forward + iron_composite_colocated_backward); the env-light branch is forward only."""
-        from .autograd import CompositeFn, any_requires_grad, refuse_grad
+        both branches (HIP forward + iron_composite_colocated_backward)."""
+        from .autograd import CompositeFn, any_requires_grad
         for k in ("metallic", "dielectric"):  # read like the reference does (KeyError if absent), then unused
             params[k]
         ins = [params[k] for k in CompositeFn.NAMES]
-        if any_requires_grad(light, distance, normal, viewdir, *ins):
+        env = params["env_light"] if use_env_light else None
+        if any_requires_grad(light, distance, normal, viewdir, env, *ins):
+            rgb, spec, met, die, env_out = CompositeFn.apply(self, light, distance, normal, viewdir, *ins, env)
+            ret = {"diffuse_rgb": rgb, "specular_rgb": spec, "metallic_rgb": met, "dielectric_rgb": die, "rgb": rgb}
             if use_env_light:
-                refuse_grad("CompositeRenderer.forward(use_env_light=True)", light, normal, viewdir, params)
-            rgb, spec, met, die = CompositeFn.apply(self, light, distance, normal, viewdir, *ins)
-            return {"diffuse_rgb": rgb, "specular_rgb": spec, "metallic_rgb": met, "dielectric_rgb": die, "rgb": rgb}
+                ret["env_light"] = env_out
+            return ret
         return self._forward_values(float(light), distance, normal, viewdir, params, use_env_light)
 
     def _forward_values(self, light, distance, normal, viewdir, params, use_env_light):

@@ -140,8 +140,7 @@ def test_training_mode_renders_the_same_image_attached_to_the_parameters():
 
 
 def test_heads_without_a_backward_refuse_inputs_that_require_grad():
-    """What has no backward (the composite env-light branch, the NeRF field's inputs) must not silently return detached results
-    inside a training graph."""
+    """What has no backward (the NeRF field's inputs) must not silently return detached results inside a training graph."""
     from iron_amd.fields import NeRF
     from iron_amd.renderer_ggx import CompositeRenderer
     z = torch.rand(8, 3, device="cuda")
@@ -156,9 +155,8 @@ def test_heads_without_a_backward_refuse_inputs_that_require_grad():
     nv = torch.nn.functional.normalize(z, dim=-1)
     params = {"diffuse_albedo": kd, "specular_albedo": z, "metallic": one, "dielectric": one, "specular_roughness": one * 0.3 + 0.05,
               "metallic_eta": one + 1, "metallic_k": one + 2, "dielectric_eta": one + 1.2, "env_light": one}
-    with pytest.raises(NotImplementedError):  # the composite head has a backward on the point-light branch only
-        CompositeRenderer(use_cuda=True)(5.0, one + 1, nv, nv, params=params, use_env_light=True)
     assert CompositeRenderer(use_cuda=True)(5.0, one + 1, nv, nv, params=params)["rgb"].requires_grad
+    assert CompositeRenderer(use_cuda=True)(5.0, one + 1, nv, nv, params=params, use_env_light=True)["env_light"].shape == (8, 1)
 
 
 @pytest.mark.parametrize("seed,sigma,yaw", [(2, 0.008, 20.0), (3, 0.012, 135.0), (4, 0.016, 250.0)])

@@ -469,11 +469,27 @@ def test_composite_backward_vs_autograd():
         assert r <= (1e-3 if k == "dielectric_eta" else 2e-5), (k, r)
         dead = ref[k] == 0
         assert float(np.abs(got[k][dead]).max() if dead.any() else 0.0) == 0.0, k  # clamped entries: exactly no gradient
-    with pytest.raises(NotImplementedError):
-        prm = {k: ins[k].cuda().requires_grad_(True) for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta",
-                                                               "metallic_k", "dielectric_eta")}
-        prm["metallic"] = prm["dielectric"] = prm["env_light"] = torch.ones(n, 1, device="cuda")
-        rend(5.0, ins["distance"].cuda(), nrm.cuda(), vd.cuda(), params=prm, use_env_light=True)
+    # the env-light branch (use_env_light=True): intensity = clamp(env_light, 1e-6, 20), returned under "env_light" as well
+    ins2 = {k: v for k, v in ins.items() if k not in ("light", "distance")}
+    ins2["env_light"] = torch.rand(n, 1, generator=gen) * 24.0 - 1.0
+    ups2 = dict(ups, env_light=torch.randn(n, 1, generator=gen))
+
+    def run_env(dev, fn):
+        v = {k: x.clone().to(dev).requires_grad_(True) for k, x in ins2.items()}
+        prm = {k: v[k] for k in ("diffuse_albedo", "specular_albedo", "specular_roughness", "metallic_eta", "metallic_k", "dielectric_eta",
+                                 "env_light")}
+        prm["metallic"] = prm["dielectric"] = torch.ones(n, 1, device=dev)
+        out = fn(v, prm)
+        sum((out[k] * u.to(dev)).sum() for k, u in ups2.items()).backward()
+        return {k: x.grad.detach().cpu().numpy() for k, x in v.items()}
+
+    dist0 = ins["distance"]
+    ref2 = run_env("cpu", lambda v, prm: R.composite_forward(5.0, dist0, v["normal"], v["viewdir"], prm, mt, md, use_env_light=True))
+    got2 = run_env("cuda", lambda v, prm: rend(5.0, dist0.cuda(), v["normal"], v["viewdir"], params=prm, use_env_light=True))
+    for k in ins2:
+        r = _rel(got2[k], ref2[k])
+        print("composite(env) d/d%s rel-L2 %.2e" % (k, r))
+        assert r <= (1e-3 if k == "dielectric_eta" else 2e-5), (k, r)
 
 
 def test_composite_training_render_vs_oracle_autograd():
