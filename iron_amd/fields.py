@@ -167,8 +167,16 @@ class SDFNetwork(_HipNet):
         return d
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
-        """[..., 3] -> [..., d_out]  (fields.py:82-98)."""
+        """[..., 3] -> [..., d_out]  (fields.py:82-98).  Under grad mode with trainable parameters the result is attached to them
+        (through the get_all operator and its backward); under torch.no_grad() -- the tracer, validation -- it is the plain kernel."""
+        if self._attached():
+            sdf, feat, _ = self.get_all(inputs, is_training=True)
+            return torch.cat([sdf, feat], dim=-1)
         return self._run(inputs, self.d_out)
+
+    def _attached(self) -> bool:
+        from .autograd import any_requires_grad
+        return any_requires_grad(*self.parameters())
 
     def _run(self, inputs: torch.Tensor, out_cols: int) -> torch.Tensor:
         x = _lib.require_cuda_f32(inputs.detach(), "inputs")
@@ -182,7 +190,10 @@ class SDFNetwork(_HipNet):
         return out.reshape(sh + [out_cols])
 
     def sdf(self, x: torch.Tensor) -> torch.Tensor:
-        """fields.py:100-101: [..., 1]; uses the sdf-only kernel (no 256-wide feature epilogue)."""
+        """fields.py:100-101: [..., 1]; uses the sdf-only kernel (no 256-wide feature epilogue) unless the result has to be
+        attached to trainable parameters (grad mode)."""
+        if self._attached():
+            return self.get_all(x, is_training=True)[0]
         return self._run(x, 1)
 
     def sdf_hidden_appearance(self, x: torch.Tensor) -> torch.Tensor:

@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 assert os.environ.get("IRON_MLP_CORE") == "f32"
 
+import torch  # noqa: E402
+
+torch.set_grad_enabled(False)  # the inference kernels (under grad mode the same calls return attached tensors)
 from iron_amd import scenes  # noqa: E402
 from iron_amd.raytracer import Camera, RayTracer, render_camera  # noqa: E402
 from iron_amd.renderer_ggx import GGXColocatedRenderer  # noqa: E402

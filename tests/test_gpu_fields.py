@@ -19,6 +19,7 @@ def s1():
     return sc, gpu
 
 
+@torch.no_grad()  # the inference kernels (under grad mode the same calls return attached tensors)
 def test_sdf_forward_matches_oracle(s1):
     """SDFNetwork.sdf / .forward on random points in [-1,1]^3 (incl. a ragged tail) vs the oracle.
     Tolerance: rel-L2 <= 1e-5 on the sdf column (stage-wise MLP tolerance)."""
@@ -36,6 +37,7 @@ def test_sdf_forward_matches_oracle(s1):
         assert np.abs(full - ref).max() <= 5e-6, n
 
 
+@torch.no_grad()  # the inference kernels (under grad mode the same calls return attached tensors)
 def test_sdf_forward_golden(s1):
     _, gpu = s1
     g = golden("g2_sdf.npz")
@@ -44,6 +46,7 @@ def test_sdf_forward_golden(s1):
     assert rel_l2(out[:256, 1:], g["feature256"]) <= 1e-5
 
 
+@torch.no_grad()  # the inference kernels (under grad mode the same calls return attached tensors)
 def test_sdf_empty_and_cpu_refused(s1):
     _, gpu = s1
     assert gpu["sdf_network"].sdf(torch.zeros(0, 3).cuda()).shape == (0, 1)
@@ -82,6 +85,7 @@ def test_ggx_golden():
     assert flips <= max(2, diff.shape[0] // 500), "table-bin flips: %d of %d" % (flips, diff.shape[0])
 
 
+@torch.no_grad()  # the inference kernels (under grad mode the same calls return attached tensors)
 def test_fp16_overflowing_weight_selects_the_fp32_core():
     """A folded weight beyond fp16's range cannot be split for the h2 core: the library keeps only the fp32 pack for that
     network and every kernel runs it on the exact-fp32 MFMA core (never a CPU path) -- results stay at parity."""

@@ -131,6 +131,15 @@ def test_sdf_gradient_eikonal_term():
     print("eikonal worst rel-L2 %.2e" % w)
     with torch.no_grad():
         assert not net.gradient(x.cuda()).requires_grad
+        plain = net(x.cuda())
+    # forward() / sdf() follow the same rule: attached under grad mode (a loss on the raw SDF values trains the network)
+    out = net(x.cuda())
+    assert out.requires_grad and net.sdf(x.cuda()).requires_grad and not plain.requires_grad
+    assert float((out.detach() - plain).abs().max()) <= 2e-6
+    sd2 = T.leaf_state(cpu_sd(nets["sdf_network"]))
+    R.sdf_forward(sd2, R.SDFSpec(), x)[:, :8].square().sum().backward()
+    out[:, :8].square().sum().backward()
+    print("forward() attached: worst rel-L2 %.2e" % _compare_param_grads(net, sd2, 2e-4, "sdf forward"))
 
 
 @pytest.mark.parametrize("name", ["diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "stage1_color"])

@@ -1,6 +1,7 @@
 """Accuracy of the HIP SDF forward vs the CPU oracle (fp32) and an fp64 evaluation of the same weights."""
 import os, sys
 import torch
+torch.set_grad_enabled(False)  # measurement / inspection of the inference kernels: nothing is attached
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from iron_amd import scenes

@@ -6,6 +6,7 @@ import sys
 import time
 
 import torch
+torch.set_grad_enabled(False)  # measurement / inspection of the inference kernels: nothing is attached
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iron_amd import scenes  # noqa: E402

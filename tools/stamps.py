@@ -8,6 +8,7 @@ import sys
 
 import numpy as np
 import torch
+torch.set_grad_enabled(False)  # measurement / inspection of the inference kernels: nothing is attached
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iron_amd import _lib, scenes  # noqa: E402
