@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/iron_train.h"
@@ -68,7 +69,15 @@ static int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, int k, cons
 // dW[out,in] = beta dW + dZ[R,out]^T X[R,in].  The output is one or two tiles while K = R is 10^5: a plain SGEMM runs it on a
 // handful of CUs, so K is split into kSplitK strided batches (partials in `partial`, [kSplitK, out*in]) that fill the chip and
 // are then summed; the < kSplitK leftover rows go through one small GEMM.
-constexpr int kSplitK = 64;
+constexpr int kSplitK = 128;  // capacity of the partial buffer; the number of splits in use is split_k()
+static int split_k() {
+    static const int v = [] {
+        const char* e = getenv("IRON_TRAIN_SPLITK");  // tuning knob (tools/train_step.py): power of two in [2, 128]
+        const int x = e ? atoi(e) : 64;
+        return x >= 2 && x <= kSplitK ? x : 64;
+    }();
+    return v;
+}
 
 __global__ void k_reduce_partials(const float* __restrict__ partial, int splits, int count, float beta, float* __restrict__ dst) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
@@ -79,14 +88,15 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, int splits,
 }
 
 static int gemm_dw(rocblas_handle h, hipStream_t st, int out, int in, int R, const float* dZ, const float* X, float beta, float* dW, float* partial) {
-    if (R < 64 * kSplitK) return gemm_rm(h, true, false, out, in, R, dZ, out, X, in, beta, dW, in);
-    const int kb = R / kSplitK;
+    const int S = split_k();
+    if (R < 64 * S) return gemm_rm(h, true, false, out, in, R, dZ, out, X, in, beta, dW, in);
+    const int kb = R / S;
     const float one = 1.0f, zero = 0.0f;
     TR_BLAS(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, in, out, kb, &one, X, in, (rocblas_stride)kb * in, dZ,
-                                          out, (rocblas_stride)kb * out, &zero, partial, in, (rocblas_stride)out * in, kSplitK));
+                                          out, (rocblas_stride)kb * out, &zero, partial, in, (rocblas_stride)out * in, S));
     const int count = out * in;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((count + 255) / 256), dim3(256), 0, st, partial, kSplitK, count, beta, dW);
-    const int done = kb * kSplitK;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((count + 255) / 256), dim3(256), 0, st, partial, S, count, beta, dW);
+    const int done = kb * S;
     if (R > done) return gemm_rm(h, true, false, out, in, R - done, dZ + (size_t)done * out, out, X + (size_t)done * in, in, 1.0f, dW, in);
     return IRON_OK;
 }
