@@ -18,6 +18,7 @@ import ctypes as C
 from typing import List, Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -84,6 +85,7 @@ class SDFGetAllFn(torch.autograd.Function):
         return sdf, feat, grad
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, d_sdf, d_feat, d_grad):
         net = ctx.net
         (x,) = ctx.saved_tensors
@@ -126,6 +128,7 @@ class RenderNetFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, d_out):
         net = ctx.net
         saved = list(ctx.saved_tensors)
@@ -194,6 +197,7 @@ class GGXColocatedFn(torch.autograd.Function):
         return out["diffuse_rgb"], out["specular_rgb"], out["rgb"]
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, g_diff, g_spec, g_rgb):
         dist, nrm, vd, kd, ks, rough = ctx.saved_tensors
         nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
@@ -254,6 +258,7 @@ class CompositeFn(torch.autograd.Function):
         return out["rgb"], out["specular_rgb"], out["metallic_rgb"], out["dielectric_rgb"], env_out
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, g_rgb, g_spec, g_met, g_die, g_env):
         nrm, vd, kd, ks, rough, m_eta, m_k, d_eta, last = ctx.saved_tensors
         nrm = _lib.require_cuda_f32(nrm, "normal").reshape(-1, 3)
@@ -332,6 +337,7 @@ class ColocHeadFn(torch.autograd.Function):
         return out["diffuse_rgb"], out["specular_rgb"], out["rgb"]
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, g_diff, g_spec, g_rgb):
         saved = list(ctx.saved_tensors)
         dist, nrm, vd, kd, ks = saved[:5]
@@ -383,6 +389,7 @@ class NeRFFn(torch.autograd.Function):
         return alpha, rgb
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, d_alpha, d_rgb):
         net = ctx.net
         pts, views = ctx.saved_tensors
@@ -458,6 +465,7 @@ class NeusCompositeFn(torch.autograd.Function):
         return out_color, weights, wsum, gerr, cdf, inside, wmax
 
     @staticmethod
+    @once_differentiable  # closed-form first-order backward: differentiating it again raises instead of returning zeros
     def backward(ctx, d_color, d_weights, d_wsum, d_gerr, _dc, _di, _dm):
         n, m, mo, bg, inv_s_value, ca, inv_s_is_tensor, s_sdf, s_grad, s_color, s_bgd, s_bgc = ctx.meta
         saved = list(ctx.saved_tensors)
