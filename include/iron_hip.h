@@ -121,6 +121,9 @@ int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, const float* vi
  *   iron_neus_merge       the sort of cat([z, new_z]) as a merge of two ascending rows, sdf carried along (:238-246)
  *   iron_neus_mid_points  section lengths, mid points and per-sample dirs of render_core (:265-277); outside != 0: the
  *                         (x/r, 1/r) parametrisation of render_core_outside (:163-172), pts [n*m,4]
+ *   iron_neus_need_background  which samples of the fed row the compositing takes from the background field: all outside samples
+ *                         and the inside samples whose mid point lies outside the unit sphere (the rest are multiplied by
+ *                         (1 - inside_sphere) = 0, :300-312); lets the caller evaluate the NeRF field on those only
  *   iron_neus_composite   render_core's alpha (logistic CDF), inside-sphere blend with the NeRF background, weights,
  *                         colour, weight_sum / weight_max, cdf, inside_sphere, eikonal statistics (:279-344, :174-178). */
 /* extract_fields' lattice (models/renderer.py:9-31): pts [nx*ny*nz,3] = meshgrid(xs, ys, zs) in 'ij' order; the field values
@@ -135,6 +138,7 @@ int iron_neus_merge(const float* z_a, const float* s_a, int32_t m_a, const float
                     float* z_out, float* s_out, void* stream);
 int iron_neus_mid_points(const float* rays_o, const float* rays_d, const float* z, int64_t n, int32_t m, float sample_dist,
                          int32_t outside, float* dists, float* pts, float* dirs, void* stream);
+int iron_neus_need_background(const float* pts, int64_t n, int32_t m, int32_t mo, uint8_t* need, void* stream);
 typedef struct iron_neus_composite_args {
     const float* dists;            /* [n,m]   section lengths of the inside samples                      */
     const float* pts;              /* [n*m,3] section mid points                                         */

@@ -104,6 +104,7 @@ SYMBOLS = {
     "iron_neus_up_sample": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P]),
     "iron_neus_merge": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I64, _P, _P, _P]),
     "iron_neus_mid_points": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P, _P, _P, _P]),
+    "iron_neus_need_background": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
     "iron_neus_composite": (C.c_int, [C.POINTER(iron_neus_composite_args), _P]),
     "iron_nerf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "iron_edge_walk": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _P, _P, _P]),

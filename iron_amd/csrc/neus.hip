@@ -155,6 +155,23 @@ __global__ void k_neus_mid_points(const float* __restrict__ o, const float* __re
     }
 }
 
+// need[r][j] = 1 where the compositing reads the background field at sample j of the fed row: every outside sample (j >= m), and an
+// inside sample only when its section mid point is NOT inside the unit sphere (renderer.py:300-312 blends with (1 - inside_sphere));
+// the same expression as k_neus_composite's `inside`, so the two can never disagree.
+__global__ void k_neus_need_background(const float* __restrict__ pts, int n, int m, int mo, uint8_t* __restrict__ need) {
+    const int64_t total = (int64_t)n * mo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / mo), j = (int)(i % mo);
+        uint8_t v = 1;
+        if (j < m) {
+            const size_t q = (size_t)r * m + j;
+            const float px = pts[3 * q], py = pts[3 * q + 1], pz = pts[3 * q + 2];
+            v = sqrtf((px * px + py * py) + pz * pz) < 1.0f ? 0 : 1;
+        }
+        need[i] = v;
+    }
+}
+
 struct NeusCompositeArgs {
     const float *dists, *pts, *dirs, *sdf, *grad, *color;  // [n*m], [n*m,3], [n*m,3], [n*m], [n*m,3], [n*m,3]
     const float *bg_dists, *bg_density, *bg_color;          // outside: [n*mo], [n*mo], [n*mo,3] or null
@@ -307,6 +324,15 @@ extern "C" int iron_neus_mid_points(const float* rays_o, const float* rays_d, co
     if (!rays_o || !rays_d || !z || !dists || !pts || !dirs) return IRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_neus_mid_points, dim3(ray_grid(n * m)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, z, (int)n, m, sample_dist,
                        outside, dists, pts, dirs);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_neus_need_background(const float* pts, int64_t n, int32_t m, int32_t mo, uint8_t* need, void* stream) {
+    if (n < 0 || m < 1 || mo < m) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!pts || !need) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_neus_need_background, dim3(ray_grid(n * mo)), dim3(64), 0, (hipStream_t)stream, pts, (int)n, m, mo, need);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

@@ -208,7 +208,16 @@ class NeuSRenderer:
             with torch.set_grad_enabled(training):
                 density = bg_color = None
                 if self.n_outside > 0:
-                    density, bg_color = self.nerf(bg_pts, bg_dirs)
+                    # The blend (:300-312) multiplies the background by (1 - inside_sphere): the field is evaluated only where that is
+                    # not zero -- the n_outside far samples and the few inside samples beyond the unit sphere -- and the rest of the
+                    # [n, n_samples + n_outside] row stays zero (the reference evaluates all of it and multiplies by 0).
+                    mo = bg_dists.shape[1]
+                    need = torch.empty((batch, mo), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.iron_neus_need_background(pts.data_ptr(), batch, n_samples, mo, need.data_ptr(), _lib.stream_ptr(dev)))
+                    idx = need.reshape(-1).nonzero(as_tuple=False).reshape(-1)
+                    d_sel, c_sel = self.nerf(bg_pts.index_select(0, idx), bg_dirs.index_select(0, idx))
+                    density = torch.zeros((batch * mo, 1), dtype=torch.float32, device=dev).index_copy(0, idx, d_sel)
+                    bg_color = torch.zeros((batch * mo, 3), dtype=torch.float32, device=dev).index_copy(0, idx, c_sel)
                 sdf, feat, grad = self.sdf_network.get_all(pts, is_training=training)
                 color = self.color_network(pts, grad, dirs, feat)
                 if training:
