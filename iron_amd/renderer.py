@@ -207,6 +207,7 @@ class NeuSRenderer:
             # render_core_outside (:151-187) and render_core (:250-344): attached to the parameters when training
             with torch.set_grad_enabled(training):
                 density = bg_color = None
+                inside_idx = None
                 if self.n_outside > 0:
                     # The blend (:300-312) multiplies the background by (1 - inside_sphere): the field is evaluated only where that is
                     # not zero -- the n_outside far samples and the few inside samples beyond the unit sphere -- and the rest of the
@@ -218,8 +219,17 @@ class NeuSRenderer:
                     d_sel, c_sel = self.nerf(bg_pts.index_select(0, idx), bg_dirs.index_select(0, idx))
                     density = torch.zeros((batch * mo, 1), dtype=torch.float32, device=dev).index_copy(0, idx, d_sel)
                     bg_color = torch.zeros((batch * mo, 3), dtype=torch.float32, device=dev).index_copy(0, idx, c_sel)
+                    # ... and the colour network's output is multiplied by inside_sphere in the same blend: it runs on the inside samples
+                    inside_idx = (need[:, :n_samples] == 0).reshape(-1).nonzero(as_tuple=False).reshape(-1)
+                    if inside_idx.numel() == batch * n_samples:
+                        inside_idx = None
                 sdf, feat, grad = self.sdf_network.get_all(pts, is_training=training)
-                color = self.color_network(pts, grad, dirs, feat)
+                if inside_idx is None:
+                    color = self.color_network(pts, grad, dirs, feat)
+                else:
+                    c_in = self.color_network(pts.index_select(0, inside_idx), grad.index_select(0, inside_idx), dirs.index_select(0, inside_idx),
+                                              feat.index_select(0, inside_idx))
+                    color = torch.zeros((batch * n_samples, 3), dtype=torch.float32, device=dev).index_copy(0, inside_idx, c_in)
                 if training:
                     inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6)
                     s_val = (1.0 / inv_s).reshape(1, 1).expand(batch, 1)
