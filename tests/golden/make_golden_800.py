@@ -4,7 +4,7 @@ Runs the real reference's render_camera (fill_holes=False, handle_edges=False) a
 what a full-size parity test needs in a small file: the complete hit mask (bit-packed), and colour / normal / distance on
 the pixel sub-lattice [::4, ::4] (40 000 pixels) for both precisions, plus the fp32-vs-fp64 floor over ALL pixels.
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_800.py
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_800.py [S0|S1]
 """
 from __future__ import annotations
 
@@ -24,10 +24,11 @@ from models.raytracer import RayTracer, render_camera  # noqa: E402  (reference)
 from models.renderer_ggx import GGXColocatedRenderer  # noqa: E402
 
 RES, STRIDE = 800, 4
+SCENE = sys.argv[1] if len(sys.argv) > 1 else "S0"  # S0: the BASELINE headline scene; S1: the bumpy one (chaotic grazing pixels)
 
 
 def run(dtype):
-    nets = MG.build_reference_networks("S0")
+    nets = MG.build_reference_networks(SCENE)
     if dtype == torch.float64:
         nets = {k: v.double() for k, v in nets.items()}
         cam32 = MG.fixture_camera(RES, RES)
@@ -56,13 +57,14 @@ def main():
     for k in ("color", "normal", "distance"):
         out[k] = r32[k].numpy()[::STRIDE, ::STRIDE].astype(np.float32)
         out[k + "_fp64"] = r64[k].numpy()[::STRIDE, ::STRIDE].astype(np.float64)
-    np.savez_compressed(os.path.join(HERE, "g12_S0_800.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "g12_%s_800.npz" % SCENE), **out)
     meta_path = os.path.join(HERE, "meta.json")
     meta = json.load(open(meta_path))
-    meta.update({"n_conv_S0_800": int(m32.sum()), "mask_flips_ref32_ref64_S0_800": int((m32 != m64).sum()),
-                 "colour_rel_l2_ref32_ref64_S0_800": floor})
+    keys = {"n_conv_%s_800" % SCENE: int(m32.sum()), "mask_flips_ref32_ref64_%s_800" % SCENE: int((m32 != m64).sum()),
+            "colour_rel_l2_ref32_ref64_%s_800" % SCENE: floor}
+    meta.update(keys)
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
-    print({k: meta[k] for k in ("n_conv_S0_800", "mask_flips_ref32_ref64_S0_800", "colour_rel_l2_ref32_ref64_S0_800")})
+    print(keys)
 
 
 if __name__ == "__main__":

@@ -222,3 +222,33 @@ def test_fullsize_vs_reference_golden(frame800):
     assert r32 <= max(1e-4, 1.5 * floor), (r32, floor)
     assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
     assert np.percentile(dist, 99) <= 2e-4
+
+
+def test_fullsize_bumpy_scene_vs_reference_golden():
+    """The same at 800x800 on scene S1 (the perturbed, bumpy SDF whose grazing pixels are chaotic) against the REAL reference
+    (tests/golden/make_golden_800.py S1): complete hit mask, colour / distance on the [::4, ::4] sub-lattice, read against the
+    reference's own fp32-vs-fp64 figures."""
+    from _util import golden, golden_meta, rel_l2
+    nets = {k: v.cuda() for k, v in scenes.build_networks("S1").items()}
+    K, W2C = scenes.fixture_camera_matrices(800, 800)
+    res = render_camera(Camera(800, 800, K.cuda(), W2C.cuda()), nets["sdf_network"], RayTracer(), nets, make_render_fn(GGXColocatedRenderer(use_cuda=True)),
+                        fill_holes=False, handle_edges=False)
+    g = golden("g12_S1_800.npz")
+    n, st = int(g["res"]), int(g["stride"])
+    mask_ref = np.unpackbits(g["mask_bits"])[: n * n].astype(bool).reshape(n, n)
+    mask64 = np.unpackbits(g["mask64_bits"])[: n * n].astype(bool).reshape(n, n)
+    conv = res["convergent_mask"].cpu().numpy()
+    flips = int((conv != mask_ref).sum())
+    flips_ref = golden_meta()["mask_flips_ref32_ref64_S1_800"]
+    sub = (slice(None, None, st), slice(None, None, st))
+    both = conv[sub] & mask_ref[sub] & mask64[sub]
+    col = res["color"].cpu().numpy()[sub]
+    r32, r64 = rel_l2(col[both], g["color"][both]), rel_l2(col[both], g["color_fp64"][both])
+    floor = rel_l2(g["color"][both], g["color_fp64"][both])
+    dist = np.abs(res["distance"].cpu().numpy()[sub][both] - g["distance"][both])
+    print("800x800 S1: mask flips %d (reference fp32 vs fp64: %d)  colour rel-L2 hip~ref32 %.3e  hip~ref64 %.3e  ref32~ref64 %.3e"
+          "  |d distance| p99 %.2e max %.2e" % (flips, flips_ref, r32, r64, floor, np.percentile(dist, 99), dist.max()))
+    assert flips <= max(4, 2 * flips_ref)
+    assert r32 <= max(1e-4, 1.5 * floor), (r32, floor)
+    assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
+    assert np.percentile(dist, 99) <= 2e-4
