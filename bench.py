@@ -8,9 +8,17 @@ pixels) on synthetic 800x800 views (BASELINE.json).
 Workload (config C1): scene S0 (seed-0 geometric-init SDF, `ggx` material nets), fixture camera
 rescaled to 800x800, tracer defaults, fill_holes=False, handle_edges=False, fp32.
   N = 1 : one step = render_camera() of one 800x800 view through the drop-in operator surface.
-  N > 1 : one step = N views (fixture pose orbited by k*45 deg), every view's rays sharded over the N ranks
-          by interleaved 32x32 tiles; one MAX all-reduce of the per-chunk bisection counts and one RCCL gather
-          of the finished pixel records to rank 0 per step.  Per-GPU work is fixed -> "scaling": "weak".
+  N > 1 : rays sharded over the N ranks by interleaved 32x32 tiles; one MAX all-reduce of the per-chunk bisection
+          counts and one RCCL gather of the finished pixel records to rank 0 per step.
+          --scaling weak (default): one step = N views (fixture pose orbited by k*45 deg, BASELINE config C4's shape),
+          every view sharded over all ranks; per-GPU work is fixed -> "scaling": "weak".
+          --scaling strong: one step = ONE view sharded over the N ranks (north_star: "rays of one render call shard by
+          image tile across the GPUs"); total work is fixed -> "scaling": "strong".
+          Whichever mode is timed as `value`, the OTHER mode is timed right after it in the same run and reported in the
+          "other_scaling" object, so one SCALE record carries both curves.
+  N = 1 also reports "predicted_strong_scaling": the 8 tile-shards of the frame run one after the other on this card
+          (iron_amd.sharding.render_emulated) -- T(frame) / max_r T(shard r) -- and "f32_core": the same workload on the
+          exact-fp32 MFMA core (a child process with IRON_MLP_CORE=f32).
 One JSON line is printed by rank 0.
 """
 from __future__ import annotations
@@ -48,6 +56,10 @@ def parse():
                     help="N=1 only: fill_holes=True, handle_edges=True (the reference's validation render, SURVEY row f-1) "
                          "instead of the headline configuration")
     ap.add_argument("--cpu-sample-res", type=int, default=160)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = N views per step, every view tile-sharded over the N ranks (default); strong = one view per step")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras of the default line (other scaling mode, 8-shard emulation, exact-fp32-core child run)")
     ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c1",
                     help="c1 (default): the BASELINE headline, 800x800 sphere-trace + GGX shade.  c2 / c3 (N=1 only): the other two "
                          "single-GPU BASELINE configurations, reported in their own units without a roofline object -- "
@@ -114,6 +126,35 @@ def cpu_baseline(scene: str, res: int):
             "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean())}
 
 
+def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms):
+    """One-GPU evidence for the multi-GPU target: the 8 (and 2, 4) tile-shards of the frame run one after the other on this
+    card through the phase methods ShardedRenderer.render() uses; T(frame) / max_r T(shard r) is the strong-scaling factor
+    load balance allows (kernel time only: the all-reduce, the gather and rank 0's un-tile come on top)."""
+    from iron_amd.sharding import render_emulated
+    out = {"frame_ms": frame_ms, "note": "T(frame) / max over shards of the shard's device time, shards run in turn on one card"}
+    for world in (2, 4, 8):
+        render_emulated(world, [cam], sdf, nets, fn, tracer_factory)
+        _, ms, asm = render_emulated(world, [cam], sdf, nets, fn, tracer_factory)
+        out["n%d" % world] = {"shard_ms": [round(x, 3) for x in ms], "max_shard_ms": max(ms), "assemble_ms": asm,
+                              "factor": frame_ms / max(ms)}
+    return out
+
+
+def f32_core_child(a):
+    """The same workload on the exact-fp32 MFMA core (IRON_MLP_CORE is read once per process: a child process)."""
+    import subprocess
+    env = dict(os.environ, IRON_MLP_CORE="f32")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--res", str(a.res), "--scene", a.scene,
+           "--no-cpu-baseline", "--no-extras"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "roofline": d["roofline"]}
+    except Exception as e:  # the headline line must not depend on the extra
+        return {"error": repr(e)}
+
+
 def main():
     a = parse()
     if a.workload != "c1":
@@ -149,11 +190,12 @@ def main():
     sdf = nets["sdf_network"]
     tracer = RayTracer()
     fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
-    n_views = world
+    n_views = world if a.scaling == "weak" else 1
     cams = []
-    for v in range(n_views):
+    for v in range(world):
         K, W2C = scenes.fixture_camera_matrices(a.res, a.res, yaw_deg=45.0 * v)
         cams.append(Camera(a.res, a.res, K.to(dev), W2C.to(dev)))
+    all_cams, cams = cams, cams[:n_views]
     sharded = ShardedRenderer(sdf, nets, tracer, fn, tile=32, chunk=50000) if world > 1 else None
 
     def step(stats=False):
@@ -194,6 +236,27 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # the other scaling mode, same run, same protocol (outside the headline's timed region)
+    other = None
+    if world > 1 and not a.no_extras:
+        o_cams = all_cams[:1] if a.scaling == "weak" else all_cams
+        for _ in range(max(1, a.warmup)):
+            sharded.render(o_cams)
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            sharded.render(o_cams)
+        torch.cuda.synchronize()
+        barrier()
+        odt = time.perf_counter() - t1
+        tmax = torch.tensor([odt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        odt = float(tmax.item())
+        other = {"scaling": "strong" if a.scaling == "weak" else "weak", "views_per_step": len(o_cams),
+                 "value": len(o_cams) * a.res * a.res * a.steps / odt / 1e6, "unit": "Mrays/s", "ms_per_step": odt / a.steps * 1e3,
+                 "steps": a.steps}
 
     # one extra (untimed) step for the work counters
     res = step(stats=True)
@@ -258,7 +321,10 @@ def main():
                 executed = {"mfma_tflops": ex / 1e12, "pipe": "f16 (fp32 = 2 x fp16 split, 3 products)" if h2 else "f32",
                             "pipe_peak": pk / 1e12, "frac_of_pipe_peak": ex / pk}
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": traffic, "core": core,
+                    "frac": ach / peak, "traffic": traffic,
+                    "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                       "(gfx950 corrections applied), NOT re-measured in this run") if traffic is not None else None,
+                    "core": core,
                     "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate MAC" if h2
                                    else "dense fp32 MFMA 157.3 TFLOP/s"),
                     "vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA, "executed": executed,
@@ -271,7 +337,7 @@ def main():
         out = {
             "metric": "Mrays/s sphere-trace+GGX shade, drv/dragon 800x800 (synthetic S0)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": a.scaling if world > 1 else "weak", "other_scaling": other, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mlp_core": os.environ.get("IRON_MLP_CORE", "h2") + (" (fp32-accurate split-fp16 MFMA, LDS weight ring)" if not os.environ.get("IRON_MLP_CORE", "h2").startswith("f") else " (exact fp32 MFMA)"),
             "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
                                    "sphere-trace + GGX shade, fp32%s" % (a.scene, a.res, a.res, " + hole filling + silhouette edge sampling" if a.edges else ""),
@@ -286,6 +352,14 @@ def main():
                       "executed_tflops": (FLOP_PER_EVAL * E_hip + FLOP_PER_HIT * H) * a.steps / dt / 1e12},
             "kernels": kernels,
         }
+        from iron_amd import build as _build
+        man = _build.manifest()
+        out["build"] = {"hipcc": man.get("hipcc"), "any_fallback_flags": man.get("any_fallback"),
+                        "units": {k: (" ".join(f for f in v["flags"] if not f.startswith("-W")) + (" [FALLBACK %d]" % v["attempt"] if v["fallback"] else ""))
+                                  for k, v in man.get("units", {}).items() if k in ("trace.hip", "shade.hip", "h2_kernels.hip")}}
+        if world == 1 and not a.no_extras and not a.edges:
+            out["predicted_strong_scaling"] = predicted_strong_scaling(cams[0], sdf, nets, fn, RayTracer, ms_per_step)
+            out["f32_core"] = f32_core_child(a)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.scene, a.cpu_sample_res)
         else:

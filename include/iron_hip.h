@@ -219,6 +219,27 @@ int iron_coloc_head(int32_t kind, float light, float eta, float k, const float* 
 int iron_morph_closing3x3(const float* depth, int32_t H, int32_t W, float* tmp, float* out, void* stream);
 int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, float* out, void* stream);
 
+/* The fill_holes update of raytrace_camera (models/raytracer.py:558-564) on the device: where the closed depth image
+ * `depth_closed` (iron_morph_closing3x3) makes a hit of a non-convergent pixel, the reference rewrites depth at those
+ * pixels, sets the mask to depth_closed > 1e-2 and recomputes distance = depth * ray_d_norm and points = ray_o + ray_d *
+ * distance for EVERY pixel -- and does nothing at all when no pixel changes.  `flag` (device int32, scratch) carries that
+ * any() between the two launches, so there is no host synchronisation.  All arrays [n] / [n,3]; conv is uint8. */
+int iron_fill_holes(const float* depth_closed, const float* ray_o, const float* ray_d, const float* ray_d_norm, int64_t n,
+                    float* depth, uint8_t* conv, float* distance, float* points, int32_t* flag, void* stream);
+
+/* render_edge_pixels (models/raytracer.py:665-729), inference form, as two launches around the side-ray trace + shade:
+ * iron_edge_sides: edge point gradients [n,3] and projections edge_uv [n,2], w2c_rot9 = W2C[:3,:3] row-major (HOST
+ * float[9]) -> side_uv [2n,2] (the n positive-side samples centre - 0.707 n2d first, then the n negative-side ones) and
+ * pos_weight [n] = 1 - (a - sin a) / 2pi, a = 2 acos(clamp(((uv - centre) . n2d) / 0.707, 0, 1)) (:680-698).
+ * iron_edge_blend: side_color [2n,3] (same order) -> color[p] = pos * w + neg * (1 - w), normal[p] = edge_grad,
+ * uv[p] = edge_uv, points[p] = edge_points at p = pixel_idx[i] (int64, flat pixel index; out-of-range entries skipped)
+ * of the [n_pixels, .] image buffers (:706-729). */
+int iron_edge_sides(const float* edge_uv, const float* edge_grad, const float* w2c_rot9, int64_t n, float* side_uv,
+                    float* pos_weight, void* stream);
+int iron_edge_blend(const float* side_color, const float* pos_weight, const float* edge_grad, const float* edge_uv,
+                    const float* edge_points, const int64_t* pixel_idx, int64_t n, int64_t n_pixels, float* color, float* normal,
+                    float* uv, float* points, void* stream);
+
 /* The surface walk of locate_edge_points (models/raytracer.py:441-478) in one launch: every start point walks along
  * the surface (step_size per step, at most max_step steps) until |n.v| <= dot_threshold seen from cam_origin3 (HOST
  * float[3]); points [n,3] receives the final positions, found [n] whether the silhouette was reached.  Needs the h2

@@ -110,6 +110,9 @@ SYMBOLS = {
     "iron_edge_walk": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _P, _P, _P]),
     "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "iron_sobel_magnitude": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "iron_fill_holes": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "iron_edge_sides": (C.c_int, [_P, _P, C.POINTER(_F), _I64, _P, _P, _P]),
+    "iron_edge_blend": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "iron_trace_workspace_bytes": (_SZ, [_I64, C.POINTER(iron_trace_params)]),
     "iron_trace": (C.c_int, [_P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                              _P, _SZ, _P]),

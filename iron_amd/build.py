@@ -6,6 +6,7 @@ travels with the tree to the GPU box.
 from __future__ import annotations
 
 import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -16,6 +17,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libiron_hip.so")
 LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/iron_train.h); links rocBLAS
 OBJ_DIR = os.path.join(CSRC, "build")
+MANIFEST = os.path.join(OBJ_DIR, "manifest.json")  # which flag set every translation unit was compiled with (bench.py echoes it)
 
 SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "neus.hip", "profile.hip"]
 TRAIN_SOURCES = ["train.hip"]
@@ -55,16 +57,29 @@ def _digest(extra_flags) -> str:
     return h.hexdigest()
 
 
+def manifest() -> dict:
+    """The flag set each translation unit of the shipped libraries was compiled with (a unit that hipcc could only build
+    with a weaker set is marked `fallback`); {} when the library was built by something else."""
+    try:
+        with open(MANIFEST) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
 def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     """Compile every .hip source and link the shared library; returns its path."""
     extra_flags = list(extra_flags) + os.environ.get("IRON_HIPCC_FLAGS", "").split()
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "stamp")
     dig = _digest(extra_flags)
-    if not force and os.path.exists(LIB) and os.path.exists(LIB_TRAIN) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if (not force and os.path.exists(LIB) and os.path.exists(LIB_TRAIN) and os.path.exists(stamp) and os.path.exists(MANIFEST)
+            and open(stamp).read() == dig):
         return LIB
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    used_flags = {}
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
@@ -76,6 +91,7 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
         for i, opt in enumerate(attempts):
             r = subprocess.run([hipcc] + BASE_FLAGS + opt + extra_flags + tail, capture_output=True, text=True)
             if r.returncode == 0:
+                used_flags[src] = {"flags": BASE_FLAGS + opt + extra_flags, "attempt": i, "fallback": i > 0}
                 break
             if verbose and i + 1 < len(attempts):
                 print("build: %s failed with [%s], retrying with [%s]" % (src, " ".join(opt), " ".join(attempts[i + 1])), file=sys.stderr)
@@ -96,6 +112,12 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for the training library:\n%s\n%s" % (r.stdout, r.stderr))
+    for src in TRAIN_SOURCES:
+        used_flags[src] = {"flags": BASE_FLAGS + extra_flags + ["-lrocblas"], "attempt": 0, "fallback": False}
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    with open(MANIFEST, "w") as f:
+        json.dump({"hipcc": ver[0] if ver else "?", "digest": dig, "units": used_flags,
+                   "any_fallback": any(u["fallback"] for u in used_flags.values())}, f, indent=1, sort_keys=True)
     with open(stamp, "w") as f:
         f.write(dig)
     if verbose:

@@ -166,6 +166,85 @@ __global__ void k_sobel(const float* __restrict__ in, int H, int W, float* __res
     }
 }
 
+// fill_holes branch of raytrace_camera (models/raytracer.py:554-564) without the host round trip of `update_mask.any()`:
+// pass 1 raises *flag when the closed depth image turns any non-convergent pixel into a hit, pass 2 applies the
+// reference's whole-image update (depth at the new hits, mask := closed > 1e-2, distance and points recomputed from the
+// depth for EVERY pixel) only if the flag is up.
+__global__ void k_fill_holes_mark(const float* __restrict__ closed, const uint8_t* __restrict__ conv, int64_t n, int* __restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) any = any || (closed[i] > 1e-2f && conv[i] == 0);
+    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void k_fill_holes_apply(const float* __restrict__ closed, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                   const float* __restrict__ ray_d_norm, int64_t n, const int* __restrict__ flag,
+                                   float* __restrict__ depth, uint8_t* __restrict__ conv, float* __restrict__ distance,
+                                   float* __restrict__ points) {
+    if (*flag == 0) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool hit = closed[i] > 1e-2f;
+        const float z = (hit && conv[i] == 0) ? closed[i] : depth[i];
+        const float t = z * ray_d_norm[i];
+        depth[i] = z;
+        conv[i] = hit ? 1 : 0;
+        distance[i] = t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) points[3 * i + c] = ray_o[3 * i + c] + ray_d[3 * i + c] * t;
+    }
+}
+
+// render_edge_pixels, geometry half (models/raytracer.py:680-698): per edge pixel the image-plane normal of the
+// silhouette, the two side samples on a circle of radius 0.707 px around the pixel centre and the area weight of the
+// positive side.  side_uv is [2n,2]: the n positive-side samples first, then the n negative-side ones.
+__global__ void k_edge_sides(const float* __restrict__ edge_uv, const float* __restrict__ edge_grad, CamMat m /* c2w unused; kinv = W2C[:3,:3] */,
+                             int64_t n, float* __restrict__ side_uv, float* __restrict__ pos_weight) {
+    const float radius = 0.707f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g[3] = {edge_grad[3 * i], edge_grad[3 * i + 1], edge_grad[3 * i + 2]};
+        const float gl = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]) + 1e-10f;
+        const float nx = g[0] / gl, ny = g[1] / gl, nz = g[2] / gl;
+        float ex = fmaf(nz, m.kinv[2], fmaf(ny, m.kinv[1], nx * m.kinv[0]));
+        float ey = fmaf(nz, m.kinv[5], fmaf(ny, m.kinv[4], nx * m.kinv[3]));
+        const float el = sqrtf(ex * ex + ey * ey) + 1e-10f;
+        ex /= el;
+        ey /= el;
+        const float u = edge_uv[2 * i], v = edge_uv[2 * i + 1];
+        const float cu = floorf(u) + 0.5f, cv = floorf(v) + 0.5f;
+        side_uv[2 * i] = cu - radius * ex;
+        side_uv[2 * i + 1] = cv - radius * ey;
+        side_uv[2 * (n + i)] = cu + radius * ex;
+        side_uv[2 * (n + i) + 1] = cv + radius * ey;
+        const float off = (u - cu) * ex + (v - cv) * ey;
+        const float alpha = 2.0f * acosf(fminf(fmaxf(off / radius, 0.0f), 1.0f));
+        pos_weight[i] = 1.0f - (alpha - sinf(alpha)) / 6.2831855f;
+    }
+}
+
+// render_edge_pixels, blend half (models/raytracer.py:706-729): colour of an edge pixel = area-weighted mix of its two
+// side samples; its normal / uv / point are those of the edge point itself.
+__global__ void k_edge_blend(const float* __restrict__ side_color /*[2n,3]*/, const float* __restrict__ pos_weight,
+                             const float* __restrict__ edge_grad, const float* __restrict__ edge_uv,
+                             const float* __restrict__ edge_points, const int64_t* __restrict__ pixel, int64_t n, int64_t n_pixels,
+                             float* __restrict__ color, float* __restrict__ normal, float* __restrict__ uv, float* __restrict__ points) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = pixel[i];
+        if (p < 0 || p >= n_pixels) continue;
+        const float w = pos_weight[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            color[3 * p + c] = side_color[3 * i + c] * w + side_color[3 * (n + i) + c] * (1.0f - w);
+            normal[3 * p + c] = edge_grad[3 * i + c];
+            points[3 * p + c] = edge_points[3 * i + c];
+        }
+        uv[2 * p] = edge_uv[2 * i];
+        uv[2 * p + 1] = edge_uv[2 * i + 1];
+    }
+}
+
 static inline int pw_grid(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -265,6 +344,46 @@ extern "C" int iron_coloc_head(int32_t kind, float light, float eta, float k, co
     if (kind == kHeadRoughConductor && !roughness) return IRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_coloc_head, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, (int)kind, light, eta, k, distance,
                        normal, viewdir, diffuse_albedo, specular_albedo, roughness, n, diffuse_rgb, specular_rgb, rgb);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_fill_holes(const float* depth_closed, const float* ray_o, const float* ray_d, const float* ray_d_norm, int64_t n,
+                               float* depth, uint8_t* conv, float* distance, float* points, int32_t* flag, void* stream) {
+    if (n < 0) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!depth_closed || !ray_o || !ray_d || !ray_d_norm || !depth || !conv || !distance || !points || !flag) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    IRON_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_fill_holes_mark, dim3(pw_grid(n)), dim3(256), 0, st, depth_closed, conv, n, (int*)flag);
+    hipLaunchKernelGGL(k_fill_holes_apply, dim3(pw_grid(n)), dim3(256), 0, st, depth_closed, ray_o, ray_d, ray_d_norm, n, (const int*)flag,
+                       depth, conv, distance, points);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_edge_sides(const float* edge_uv, const float* edge_grad, const float* w2c_rot9, int64_t n, float* side_uv,
+                               float* pos_weight, void* stream) {
+    if (n < 0 || !w2c_rot9) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!edge_uv || !edge_grad || !side_uv || !pos_weight) return IRON_ERR_BAD_ARG;
+    CamMat m;
+    for (int i = 0; i < 9; ++i) m.kinv[i] = w2c_rot9[i];
+    for (int i = 0; i < 12; ++i) m.c2w[i] = 0.0f;
+    hipLaunchKernelGGL(k_edge_sides, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, edge_uv, edge_grad, m, n, side_uv, pos_weight);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_edge_blend(const float* side_color, const float* pos_weight, const float* edge_grad, const float* edge_uv,
+                               const float* edge_points, const int64_t* pixel_idx, int64_t n, int64_t n_pixels, float* color,
+                               float* normal, float* uv, float* points, void* stream) {
+    if (n < 0 || n_pixels < 0) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!side_color || !pos_weight || !edge_grad || !edge_uv || !edge_points || !pixel_idx || !color || !normal || !uv || !points)
+        return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_edge_blend, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, side_color, pos_weight, edge_grad, edge_uv,
+                       edge_points, pixel_idx, n, n_pixels, color, normal, uv, points);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

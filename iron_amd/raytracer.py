@@ -138,12 +138,12 @@ class RayTracer(nn.Module):
 
 
     @torch.no_grad()
-    def forward_phased(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, reduce_fn,
-                       collect_stats: bool = False):
-        """Multi-rank form of forward(): the rays of one reference chunk may live on several ranks, so the
-        chunk-global bisection count is exchanged between the two halves.  `ray_index` [n] int64 = position of
-        each ray in the whole job (chunk id = ray_index // chunk); `reduce_fn(int32[n_chunks])` must MAX-reduce
-        the table over the ranks in place (iron_amd.sharding.reduce_chunk_iters)."""
+    def phase_begin(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, collect_stats: bool = False):
+        """First half of the multi-rank form of forward(): sphere tracing, dense sampling and each ray's own bisection
+        (iron_trace_phase 0).  The rays of one reference chunk may live on several ranks, so the chunk-global bisection count
+        (raytracer.py:204-217) has to be MAX-reduced over the ranks before the second half runs.  `ray_index` [n] int64 =
+        position of each ray in the whole job (chunk id = ray_index // chunk).  Returns the state phase_finish() takes;
+        state["chunk_iters"] (int32 [n_chunks], device) is the table to reduce in place."""
         o = _lib.require_cuda_f32(ray_o, "ray_o").reshape(-1, 3)
         net = _resolve_sdf_network(sdf, o.device)
         d = _lib.require_cuda_f32(ray_d, "ray_d").reshape(-1, 3)
@@ -155,10 +155,10 @@ class RayTracer(nn.Module):
             raise _lib.IronError("ray_index must be a CUDA int64 tensor")
         n = o.shape[0]
         dev = o.device
-        conv = torch.empty(n, dtype=torch.bool, device=dev)
-        points = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        sdf_out = torch.empty(n, dtype=torch.float32, device=dev)
-        dist = torch.empty(n, dtype=torch.float32, device=dev)
+        out = {"convergent_mask": torch.empty(n, dtype=torch.bool, device=dev),
+               "points": torch.empty((n, 3), dtype=torch.float32, device=dev),
+               "sdf": torch.empty(n, dtype=torch.float32, device=dev),
+               "distance": torch.empty(n, dtype=torch.float32, device=dev)}
         chunk_iters = torch.zeros(int(n_chunks), dtype=torch.int32, device=dev)
         lib = _lib.load()
         prm = self._params(chunk)
@@ -168,17 +168,34 @@ class RayTracer(nn.Module):
         lin = _linspace_steps(self.n_steps, dev)
         args = (net.hip_net().handle, C.byref(prm), lin.data_ptr(), o.data_ptr(), d.data_ptr(), near.data_ptr(),
                 far.data_ptr(), work.data_ptr(), idx.data_ptr(), n, chunk_iters.data_ptr(), int(n_chunks),
-                conv.data_ptr(), points.data_ptr(), sdf_out.data_ptr(), dist.data_ptr(), _lib.ptr(stats),
-                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
-        with torch.cuda.device(dev):
-            if n > 0:
+                out["convergent_mask"].data_ptr(), out["points"].data_ptr(), out["sdf"].data_ptr(), out["distance"].data_ptr(),
+                _lib.ptr(stats), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+        state = {"args": args, "keep": (prm, lin, o, d, near, far, work, idx, ws), "n": n, "device": dev, "out": out,
+                 "chunk_iters": chunk_iters, "stats": stats}
+        if n > 0:
+            with torch.cuda.device(dev):
                 _lib.check(lib.iron_trace_phase(0, *args))
-            reduce_fn(chunk_iters)
-            if n > 0:
-                _lib.check(lib.iron_trace_phase(1, *args))
-        if collect_stats:
-            self.last_stats = dict(zip(_lib.TRACE_STATS_FIELDS, stats.cpu().tolist()))
-        return {"convergent_mask": conv, "points": points, "sdf": sdf_out, "distance": dist}
+        return state
+
+    @torch.no_grad()
+    def phase_finish(self, state):
+        """Second half: every bracketed ray runs up to its chunk's (reduced) iteration count, then the final mid-point
+        evaluation (iron_trace_phase 1).  Returns the result dict of forward()."""
+        if state["n"] > 0:
+            with torch.cuda.device(state["device"]):
+                _lib.check(_lib.load().iron_trace_phase(1, *state["args"]))
+        if state["stats"] is not None:
+            self.last_stats = dict(zip(_lib.TRACE_STATS_FIELDS, state["stats"].cpu().tolist()))
+        return state["out"]
+
+    @torch.no_grad()
+    def forward_phased(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, reduce_fn,
+                       collect_stats: bool = False):
+        """phase_begin -> reduce_fn(int32[n_chunks]) (MAX over the ranks, in place: iron_amd.sharding.reduce_chunk_iters)
+        -> phase_finish."""
+        state = self.phase_begin(sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, collect_stats)
+        reduce_fn(state["chunk_iters"])
+        return self.phase_finish(state)
 
 
 @torch.no_grad()
@@ -211,6 +228,7 @@ class Camera(object):
         self.C2W = torch.inverse(W2C.detach().float().cpu()).to(self.device)
         self._kinv_host = (C.c_float * 9)(*self.K_inv[:3, :3].cpu().reshape(-1).tolist())
         self._c2w_host = (C.c_float * 12)(*self.C2W[:3, :4].cpu().reshape(-1).tolist())
+        self._w2c_rot_host = (C.c_float * 9)(*W2C.detach().float()[:3, :3].cpu().reshape(-1).tolist())
 
     def get_rays(self, uv):
         """uv [..., 2] -> ray_o [...,3], ray_d [...,3] (unit), ray_d_norm [...] (raytracer.py:254-286)."""
@@ -248,39 +266,44 @@ class Camera(object):
         uv = uv[:, :2] / uv[:, 2:3]
         return uv.view(sh + [2])
 
-    def crop_region(self, trgt_W, trgt_H, center_crop=False, ul_corner=None, image=None, mask=None):
-        """raytracer.py:327-351 -> (camera, image, mask)."""
-        K = self.K.clone()
+    def _crop_origin(self, trgt_W, trgt_H, center_crop, ul_corner):
+        """(column, row) of the crop window's upper-left pixel.  The random draws consume numpy's global generator exactly
+        like raytracer.py:331-338: column first, then row."""
         if ul_corner is not None:
-            ul_col, ul_row = ul_corner
-        elif center_crop:
-            ul_col = self.W // 2 - trgt_W // 2 - np.random.randint(0, 256)
-            ul_row = self.H // 2 - trgt_H // 2 - np.random.randint(0, 256)
-        else:
-            ul_col = np.random.randint(0, self.W - trgt_W)
-            ul_row = np.random.randint(0, self.H - trgt_H)
-        K[0, 2] -= ul_col
-        K[1, 2] -= ul_row
-        camera = Camera(trgt_W, trgt_H, K, self.W2C.clone())
-        if image is not None:
-            assert image.shape[0] == self.H and image.shape[1] == self.W, "image size does not match specified size"
-            image = image[ul_row: ul_row + trgt_H, ul_col: ul_col + trgt_W]
-        if mask is not None:
-            assert mask.shape[0] == self.H and mask.shape[1] == self.W, "mask size does not match specified size"
-            mask = mask[ul_row: ul_row + trgt_H, ul_col: ul_col + trgt_W]
-        return camera, image, mask
+            return int(ul_corner[0]), int(ul_corner[1])
+        if center_crop:  # a window around the centre, pushed up / left by less than 256 pixels
+            jitter = [int(np.random.randint(0, 256)) for _ in range(2)]
+            return self.W // 2 - trgt_W // 2 - jitter[0], self.H // 2 - trgt_H // 2 - jitter[1]
+        return int(np.random.randint(0, self.W - trgt_W)), int(np.random.randint(0, self.H - trgt_H))
+
+    def crop_region(self, trgt_W, trgt_H, center_crop=False, ul_corner=None, image=None, mask=None):
+        """raytracer.py:327-351 -> (camera, image, mask): the sub-window's camera is this one with the principal point moved
+        by the window origin; `image` / `mask` ([H,W,...]) are cut to the same window."""
+        col0, row0 = self._crop_origin(trgt_W, trgt_H, center_crop, ul_corner)
+        principal_shift = torch.zeros_like(self.K)
+        principal_shift[0, 2] = col0
+        principal_shift[1, 2] = row0
+        sub = Camera(trgt_W, trgt_H, self.K - principal_shift, self.W2C.clone())
+        window = (slice(row0, row0 + trgt_H), slice(col0, col0 + trgt_W))
+        cut = []
+        for label, img in (("image", image), ("mask", mask)):
+            if img is not None:
+                if img.shape[0] != self.H or img.shape[1] != self.W:
+                    raise AssertionError("%s size does not match specified size" % label)
+                img = img[window]
+            cut.append(img)
+        return sub, cut[0], cut[1]
 
     def resize(self, factor, image=None):
-        """raytracer.py:353-364 -> (camera, image).  Image resampling (cv2.INTER_AREA in the reference) is
-        dataset I/O, out of scope here."""
-        trgt_H, trgt_W = int(self.H * factor), int(self.W * factor)
-        K = self.K.clone()
-        K[0, :3] *= trgt_W / self.W
-        K[1, :3] *= trgt_H / self.H
-        camera = Camera(trgt_W, trgt_H, K, self.W2C.clone())
+        """raytracer.py:353-364 -> (camera, image): intrinsics rows 0 / 1 scaled by the (integer-truncated) size ratio.
+        Resampling an image (cv2.INTER_AREA in the reference) is dataset I/O and out of scope here."""
         if image is not None:
             raise NotImplementedError("Camera.resize(image=...) needs cv2.INTER_AREA resampling (dataset I/O, out of scope)")
-        return camera, image
+        new_H, new_W = int(self.H * factor), int(self.W * factor)
+        K = self.K.clone()
+        for row, ratio in ((0, new_W / self.W), (1, new_H / self.H)):
+            K[row, :3] = K[row, :3] * ratio
+        return Camera(new_W, new_H, K, self.W2C.clone()), None
 
 
 @torch.no_grad()
@@ -306,11 +329,13 @@ def raytrace_pixels(sdf_network, raytracer, uv, camera, mask=None, max_num_rays=
 
 
 def unique(x, dim=-1):
-    """raytracer.py:412-419: unique elements of x and, for each, the index of its FIRST occurrence in x."""
-    uniq, inverse = torch.unique(x, return_inverse=True, dim=dim)
-    perm = torch.arange(inverse.size(dim), dtype=inverse.dtype, device=inverse.device)
-    inverse, perm = inverse.flip([dim]), perm.flip([dim])
-    return uniq, inverse.new_empty(uniq.size(dim)).scatter_(dim, inverse, perm)
+    """raytracer.py:412-419: the unique elements of x along `dim` and, for each, the index of its FIRST occurrence in x
+    (a min-reduction over the positions that map to each unique element: deterministic on the GPU)."""
+    values, group = torch.unique(x, return_inverse=True, dim=dim)
+    n = x.size(dim)
+    position = torch.arange(n, dtype=group.dtype, device=group.device)
+    first = torch.full((values.size(dim),), n, dtype=group.dtype, device=group.device)
+    return values, first.scatter_reduce_(0, group.reshape(-1), position, reduce="amin", include_self=True)
 
 
 def morph_closing3x3(depth):
@@ -404,41 +429,70 @@ def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_si
     return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
 
 
+def fill_depth_holes(results):
+    """The fill_holes branch of raytrace_camera (raytracer.py:554-564), in place and without a host round trip:
+    morphological closing of the depth image, then -- only if that turns some non-convergent pixel into a hit -- depth at
+    the new hits, mask = closed depth > 1e-2, and distance / points recomputed from the depth for every pixel
+    (iron_morph_closing3x3 + iron_fill_holes)."""
+    depth = results["depth"]
+    closed = morph_closing3x3(depth)
+    dev = depth.device
+    n = depth.numel()
+    conv = results["convergent_mask"]
+    if not conv.is_contiguous():
+        conv = results["convergent_mask"] = conv.contiguous()
+    for k in ("depth", "distance", "points"):
+        if not results[k].is_contiguous():
+            results[k] = results[k].contiguous()
+    ray_o = _lib.require_cuda_f32(results["ray_o"], "ray_o")
+    ray_d = _lib.require_cuda_f32(results["ray_d"], "ray_d")
+    nrm = _lib.require_cuda_f32(results["ray_d_norm"], "ray_d_norm")
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().iron_fill_holes(closed.data_ptr(), ray_o.data_ptr(), ray_d.data_ptr(), nrm.data_ptr(), n,
+                                               results["depth"].data_ptr(), conv.data_ptr(), results["distance"].data_ptr(),
+                                               results["points"].data_ptr(), flag.data_ptr(), _lib.stream_ptr(dev)))
+
+
+def silhouette_candidates(results):
+    """raytracer.py:566-570: hit pixels whose depth changes by more than 1e-2 per pixel (normalised sobel magnitude)."""
+    magnitude = sobel_magnitude(results["depth"])
+    return magnitude, (magnitude > 1e-2) & results["convergent_mask"]
+
+
 @torch.no_grad()
 def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=False, detect_edges=False,
                     depth_edge_mask=None):
     """raytracer.py:542-590.  `depth_edge_mask` (extension, tests only) replaces the sobel-derived candidate mask."""
     results = raytrace_pixels(sdf_network, raytracer, camera.get_uv(), camera, max_num_rays=max_num_rays)
     results["depth"] *= results["convergent_mask"].float()
-
     if fill_holes:
-        depth = morph_closing3x3(results["depth"])
-        new_convergent_mask = depth > 1e-2
-        update_mask = new_convergent_mask & (~results["convergent_mask"])
-        if update_mask.any():
-            results["depth"][update_mask] = depth[update_mask]
-            results["convergent_mask"] = new_convergent_mask
-            results["distance"] = results["depth"] * results["ray_d_norm"]
-            results["points"] = results["ray_o"] + results["ray_d"] * results["distance"].unsqueeze(-1)
-
+        fill_depth_holes(results)
     if detect_edges:
-        depth_grad_norm = None
-        if depth_edge_mask is None:
-            depth_grad_norm = sobel_magnitude(results["depth"])
-            depth_edge_mask = (depth_grad_norm > 1e-2) & results["convergent_mask"]
-        results.update(locate_edge_points(camera, results["points"], sdf_network, max_step=16, step_size=1e-3,
-                                          dot_threshold=5e-2, max_num_rays=max_num_rays, mask=depth_edge_mask))
-        results["convergent_mask"] &= ~results["edge_mask"]
-        if VERBOSE_MODE and depth_grad_norm is not None:
-            results.update({"depth_grad_norm": depth_grad_norm, "depth_edge_mask": depth_edge_mask})
+        locate_silhouette(results, camera, sdf_network, max_num_rays, depth_edge_mask)
     return results
 
 
+def locate_silhouette(results, camera, sdf_network, max_num_rays=200000, depth_edge_mask=None):
+    """The detect_edges branch (raytracer.py:566-588): candidates -> surface walk -> one edge point per pixel; edge pixels
+    leave the convergent mask.  Shared by raytrace_camera and the sharded renderer's post-pass."""
+    magnitude = None
+    if depth_edge_mask is None:
+        magnitude, depth_edge_mask = silhouette_candidates(results)
+    results.update(locate_edge_points(camera, results["points"], sdf_network, max_step=16, step_size=1e-3,
+                                      dot_threshold=5e-2, max_num_rays=max_num_rays, mask=depth_edge_mask))
+    results["convergent_mask"] &= ~results["edge_mask"]
+    if VERBOSE_MODE and magnitude is not None:
+        results["depth_grad_norm"], results["depth_edge_mask"] = magnitude, depth_edge_mask
+
+
 def reparam_points(nondiff_points, nondiff_grads, nondiff_trgt_dirs, diff_sdf_vals):
-    """raytracer.py:17-24: the tracer's (non-differentiable) hit point as a function of the SDF parameters."""
-    dot = (nondiff_grads * nondiff_trgt_dirs).sum(dim=-1, keepdim=True)
-    dot = torch.clamp(dot, min=1e-4)
-    return nondiff_points - nondiff_trgt_dirs / dot * (diff_sdf_vals - diff_sdf_vals.detach())
+    """raytracer.py:17-24: re-attach a traced (non-differentiable) surface point to the SDF parameters.  Moving the
+    parameters moves the zero level set along `nondiff_trgt_dirs` by -d(sdf) / (grad . dir); the residual below is zero in
+    value and carries exactly that derivative.  The slope is clamped at 1e-4 (rays grazing the surface)."""
+    slope = (nondiff_grads * nondiff_trgt_dirs).sum(dim=-1, keepdim=True).clamp(min=1e-4)
+    residual = diff_sdf_vals - diff_sdf_vals.detach()
+    return nondiff_points - (nondiff_trgt_dirs / slope) * residual
 
 
 def render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=False, max_num_pts=320000):
@@ -483,56 +537,89 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
         results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
 
 
-def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=False):
-    """raytracer.py:665-729: one ray on each side of every edge pixel, blended by the area the edge cuts off
-    the (circular, r = 0.707) pixel; mutates `results`."""
-    edge_points, edge_uv, edge_pixel_idx = results["edge_points"], results["edge_uv"], results["edge_pixel_idx"]
-    edge_pixel_center = torch.floor(edge_uv) + 0.5
+PIXEL_RADIUS = 0.707  # a pixel taken as a disc of radius sqrt(2)/2 (raytracer.py:691-693)
 
-    if is_training:
-        # row f-2: the edge point moves with the SDF parameters along its normal, so the blend weight is in the graph
-        edge_sdf, _, edge_grads = sdf_network.get_all(edge_points, is_training=True)
-    else:
-        _, edge_grads = sdf_network.get_sdf_and_gradient(edge_points)
-    edge_normals = edge_grads.detach() / (edge_grads.detach().norm(dim=-1, keepdim=True) + 1e-10)
-    if is_training:
-        edge_points = reparam_points(edge_points, edge_grads.detach(), edge_normals, edge_sdf)
-        edge_uv = camera.project(edge_points)
-    edge_normals2d = torch.matmul(edge_normals, camera.W2C[:3, :3].transpose(1, 0))[:, :2]
-    edge_normals2d = edge_normals2d / (edge_normals2d.norm(dim=-1, keepdim=True) + 1e-10)
 
-    pixel_radius = 0.707
-    pos_side_uv = edge_pixel_center - pixel_radius * edge_normals2d
-    neg_side_uv = edge_pixel_center + pixel_radius * edge_normals2d
-    dot2d = torch.sum((edge_uv - edge_pixel_center) * edge_normals2d, dim=-1)
-    alpha = 2 * torch.arccos(torch.clamp(dot2d / pixel_radius, min=0.0, max=1.0))
-    pos_side_weight = 1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)
-
-    n_edge = edge_uv.shape[0]
-    if 0 < n_edge <= 200000:
-        # Both side-ray batches through ONE launch sequence: with chunk = n_edge the tracer treats rays [0, n) and
-        # [n, 2n) as two separate reference calls (own bisection counts, raytracer.py:204-217), and shading is
-        # per point, so this equals the reference's two raytrace_pixels + two render_normal_and_color calls while
-        # halving the chain of small dependent launches.
-        both = raytrace_pixels(sdf_network, raytracer, torch.cat([pos_side_uv, neg_side_uv], dim=0), camera,
-                               max_num_rays=n_edge)
+def _side_rays(results_of, n_edge, sdf_network, raytracer, camera, side_uv, color_network_dict, render_fn, is_training):
+    """Trace + shade the 2n side samples ([2n,2] uv: positive side first).  One launch sequence for both sides: with
+    chunk = n the tracer keeps rays [0,n) and [n,2n) apart as two reference calls (own bisection counts,
+    raytracer.py:204-217) and shading is per point, so this equals the reference's two raytrace_pixels + two
+    render_normal_and_color calls."""
+    if n_edge <= 200000:
+        both = raytrace_pixels(sdf_network, raytracer, side_uv, camera, max_num_rays=n_edge)
         render_normal_and_color(both, sdf_network, color_network_dict, render_fn, is_training=is_training)
-        pos_side_results = {k: v[:n_edge] for k, v in both.items()}
-        neg_side_results = {k: v[n_edge:] for k, v in both.items()}
-    else:
-        pos_side_results = raytrace_pixels(sdf_network, raytracer, pos_side_uv, camera)
-        neg_side_results = raytrace_pixels(sdf_network, raytracer, neg_side_uv, camera)
-        render_normal_and_color(pos_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
-        render_normal_and_color(neg_side_results, sdf_network, color_network_dict, render_fn, is_training=is_training)
+        return both
+    halves = []
+    for part in (side_uv[:n_edge], side_uv[n_edge:]):
+        r = raytrace_pixels(sdf_network, raytracer, part, camera)
+        render_normal_and_color(r, sdf_network, color_network_dict, render_fn, is_training=is_training)
+        halves.append(r)
+    return {k: torch.cat([halves[0][k], halves[1][k]], dim=0) for k in halves[0]}
 
-    edge_color = (pos_side_results["color"] * pos_side_weight.unsqueeze(-1)
-                  + neg_side_results["color"] * (1.0 - pos_side_weight.unsqueeze(-1)))
-    results["color"].view(-1, 3)[edge_pixel_idx] = edge_color
-    results["normal"].view(-1, 3)[edge_pixel_idx] = edge_grads
-    results["edge_pos_neg_normal"] = torch.cat([pos_side_results["normal"][pos_side_results["convergent_mask"]],
-                                                neg_side_results["normal"][neg_side_results["convergent_mask"]]], dim=0)
-    results["uv"].view(-1, 2)[edge_pixel_idx] = edge_uv.detach()
-    results["points"].view(-1, 3)[edge_pixel_idx] = edge_points.detach()
+
+def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=False):
+    """raytracer.py:665-729: one ray on each side of every edge pixel, blended by the area the silhouette cuts off the pixel
+    disc; mutates `results` (color, normal, uv, points at the edge pixels; edge_pos_neg_normal).
+    Inference: iron_edge_sides -> side-ray trace + shade -> iron_edge_blend, no elementwise torch chain.
+    is_training=True (row f-2): the same geometry as torch expressions, because the blend weight and both side colours
+    carry gradients to the SDF parameters (the edge point is re-attached with reparam_points)."""
+    n_edge = int(results["edge_uv"].shape[0])
+    if n_edge == 0:
+        results["edge_pos_neg_normal"] = results["normal"].new_zeros((0, 3))
+        return
+    if is_training:
+        return _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn)
+    dev = results["edge_uv"].device
+    edge_points = _lib.require_cuda_f32(results["edge_points"], "edge_points")
+    edge_uv = _lib.require_cuda_f32(results["edge_uv"], "edge_uv")
+    pixel = results["edge_pixel_idx"].contiguous()
+    _, edge_grads = sdf_network.get_sdf_and_gradient(edge_points)
+    edge_grads = edge_grads.contiguous()
+    side_uv = torch.empty((2 * n_edge, 2), dtype=torch.float32, device=dev)
+    weight = torch.empty(n_edge, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.iron_edge_sides(edge_uv.data_ptr(), edge_grads.data_ptr(), camera._w2c_rot_host, n_edge, side_uv.data_ptr(),
+                                       weight.data_ptr(), _lib.stream_ptr(dev)))
+    both = _side_rays(results, n_edge, sdf_network, raytracer, camera, side_uv, color_network_dict, render_fn, False)
+    side_color = _lib.require_cuda_f32(both["color"], "color").reshape(2 * n_edge, 3)
+    for k in ("color", "normal", "uv", "points"):
+        if not results[k].is_contiguous():
+            results[k] = results[k].contiguous()
+    n_pixels = results["color"].numel() // 3
+    with torch.cuda.device(dev):
+        _lib.check(lib.iron_edge_blend(side_color.data_ptr(), weight.data_ptr(), edge_grads.data_ptr(), edge_uv.data_ptr(),
+                                       edge_points.data_ptr(), pixel.data_ptr(), n_edge, n_pixels, results["color"].data_ptr(),
+                                       results["normal"].data_ptr(), results["uv"].data_ptr(), results["points"].data_ptr(),
+                                       _lib.stream_ptr(dev)))
+    results["edge_pos_neg_normal"] = both["normal"][both["convergent_mask"]]
+
+
+def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn):
+    pixel = results["edge_pixel_idx"]
+    anchor = results["edge_points"]
+    centre = results["edge_uv"].floor() + 0.5
+    sdf_at_edge, _, grads = sdf_network.get_all(anchor, is_training=True)
+    g = grads.detach()
+    unit = g / (g.norm(dim=-1, keepdim=True) + 1e-10)
+    # the edge point slides along its normal with the parameters, and so does its projection
+    moving = reparam_points(anchor, g, unit, sdf_at_edge)
+    moving_uv = camera.project(moving)
+    in_plane = (unit @ camera.W2C[:3, :3].t())[:, :2]
+    in_plane = in_plane / (in_plane.norm(dim=-1, keepdim=True) + 1e-10)
+    offset = PIXEL_RADIUS * in_plane
+    n_edge = anchor.shape[0]
+    both = _side_rays(results, n_edge, sdf_network, raytracer, camera, torch.cat([centre - offset, centre + offset], dim=0),
+                      color_network_dict, render_fn, True)
+    # circular-segment area on the positive side of a chord at signed distance h from the centre, as a fraction of the disc
+    h = ((moving_uv - centre) * in_plane).sum(dim=-1)
+    angle = 2 * torch.arccos((h / PIXEL_RADIUS).clamp(min=0.0, max=1.0))
+    w = (1.0 - (angle - torch.sin(angle)) / (2.0 * np.pi)).unsqueeze(-1)
+    results["color"].view(-1, 3)[pixel] = both["color"][:n_edge] * w + both["color"][n_edge:] * (1.0 - w)
+    results["normal"].view(-1, 3)[pixel] = grads
+    results["edge_pos_neg_normal"] = both["normal"][both["convergent_mask"]]
+    results["uv"].view(-1, 2)[pixel] = moving_uv.detach()
+    results["points"].view(-1, 3)[pixel] = moving.detach()
 
 
 def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes=False, handle_edges=True,

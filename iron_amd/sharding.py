@@ -107,22 +107,63 @@ def assemble_views(parts: Sequence[torch.Tensor], pix_lists: Sequence[torch.Tens
     return out.reshape(n_views, H, W, Cw)
 
 
-def split_record(img: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """[..., RECORD_WIDTH] -> result dict with the reference's keys / dtypes."""
+def split_record(img: torch.Tensor, layout=None) -> Dict[str, torch.Tensor]:
+    """[..., width] -> result dict with the reference's keys / dtypes (layout: RECORD unless given)."""
     out, o = {}, 0
-    for k, w in RECORD:
+    for k, w in (layout or RECORD):
         v = img[..., o:o + w]
         o += w
         out[k] = (v[..., 0] > 0.5) if k == "convergent_mask" else (v[..., 0] if w == 1 else v)
     return out
 
 
+def all_gather_records(local: torch.Tensor, sizes: Sequence[int], group=None) -> List[torch.Tensor]:
+    """Every rank receives every rank's [n_r, C] buffer (padded to the largest shard for the collective)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [local]
+    world = dist.get_world_size(group)
+    n_max = max(sizes)
+    dev = local.device
+    if _via_host(local, group):
+        local = local.cpu()
+    buf = local
+    if local.shape[0] != n_max:
+        buf = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        buf[: local.shape[0]] = local
+    buf = buf.contiguous()
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [o[: sizes[r]].to(dev) for r, o in enumerate(outs)]
+
+
+# what the fill_holes pass needs of the whole image from every rank (floats per pixel)
+TRACE_RECORD = (("convergent_mask", 1), ("depth", 1), ("distance", 1), ("sdf", 1), ("points", 3))
+TRACE_WIDTH = sum(w for _, w in TRACE_RECORD)
+SHADE_KEYS = ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo", "specular_roughness", "normal")
+
+
+def _pack(res: Dict[str, torch.Tensor], layout, rows: int) -> torch.Tensor:
+    cols = []
+    for k, w in layout:
+        v = res[k]
+        cols.append((v.float() if v.dtype == torch.bool else v).reshape(rows, w))
+    return torch.cat(cols, dim=1).contiguous()
+
+
 class ShardedRenderer:
-    """render_camera (fill_holes=False, handle_edges=False, is_training=False) for a batch of views, with the
-    rays of every view tile-sharded over the ranks of `group`.  The result dicts arrive on rank 0."""
+    """render_camera(is_training=False) for a batch of views with the rays of every view tile-sharded over the ranks of
+    `group`; the result dicts arrive on rank 0.  Exchanges per call: the MAX all-reduce of the chunk bisection counts, one
+    gather of the finished pixel records, and -- with fill_holes only -- one all-gather of the 7-float trace records,
+    because the reference's hole filling (raytracer.py:554-564) is a whole-image pass that rewrites distance and points of
+    EVERY pixel before shading: each rank applies it to the assembled image and shades its own tiles from the result.
+    Silhouette edge sampling (handle_edges: sobel, surface walk, side rays: a few thousand rays) runs on rank 0 after the
+    gather.
+
+    `world` / `rank` override the process group's: shard emulation on one card (tests/test_gpu_shards.py, tools/
+    shard_scaling.py drive the phase methods of `world` instances by hand and do the exchanges in memory)."""
 
     def __init__(self, sdf_network, color_network_dict, raytracer, render_fn, tile: int = 32, chunk: int = 50000,
-                 group=None):
+                 group=None, world: Optional[int] = None, rank: Optional[int] = None):
         self.sdf_network = sdf_network
         self.nets = color_network_dict
         self.tracer = raytracer
@@ -130,8 +171,11 @@ class ShardedRenderer:
         self.tile = tile
         self.chunk = chunk
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if world is not None:
+            self.world, self.rank = int(world), int(rank or 0)
+        else:
+            self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if self.world > 1 else 0
         self._pix_cache = {}
         self.last_stats = None
 
@@ -144,15 +188,16 @@ class ShardedRenderer:
             self._pix_cache[key] = (lists, mine, uv)
         return self._pix_cache[key]
 
+    # ---- phases (each is local to the rank; the exchanges sit between them) -------------------------------------------
     @torch.no_grad()
-    def render(self, cameras, collect_stats: bool = False):
+    def trace_begin(self, cameras, collect_stats: bool = False):
+        """This rank's rays of every view, sphere intersection, tracer phase 0.  state["chunk_iters"] is the table to
+        MAX-reduce over the ranks before trace_finish."""
         from .raytracer import SDFHandle, intersect_sphere
         H, W = cameras[0].H, cameras[0].W
         dev = cameras[0].device
         lists, mine, uv = self._pix(H, W, dev)
         V = len(cameras)
-        n_r = mine.numel()
-        # 1. this rank's rays of every view
         o_parts, d_parts, nrm_parts, idx_parts = [], [], [], []
         for v, cam in enumerate(cameras):
             ro, rd, rn = cam.get_rays(uv)
@@ -161,27 +206,136 @@ class ShardedRenderer:
         ray_o, ray_d, ray_n = torch.cat(o_parts), torch.cat(d_parts), torch.cat(nrm_parts)
         ray_index = torch.cat(idx_parts).contiguous()
         hit, near, far = intersect_sphere(ray_o, ray_d, 1.0)
-        # 2. tracer phase 0 -> MAX all-reduce of the chunk counts -> phase 1
         n_chunks = V * chunks_per_view(H, W, self.chunk)
-        res = self.tracer.forward_phased(SDFHandle(self.sdf_network), ray_o, ray_d, near, far, hit, ray_index, n_chunks,
-                                         self.chunk, lambda t: reduce_chunk_iters(t, self.group), collect_stats)
+        st = self.tracer.phase_begin(SDFHandle(self.sdf_network), ray_o, ray_d, near, far, hit, ray_index, n_chunks, self.chunk,
+                                     collect_stats)
+        st.update({"cameras": cameras, "ray_o": ray_o, "ray_d": ray_d, "ray_n": ray_n, "V": V, "H": H, "W": W, "lists": lists,
+                   "mine": mine, "n_r": int(mine.numel())})
+        return st
+
+    @torch.no_grad()
+    def trace_finish(self, st):
+        res = self.tracer.phase_finish(st)
         self.last_stats = self.tracer.last_stats
-        res["depth"] = res["distance"] / ray_n * res["convergent_mask"].float()  # raytracer.py:393,552
-        res.update({"ray_o": ray_o, "ray_d": ray_d})
-        # 3. shade (fused kernels when render_fn is the GGX one)
+        res["depth"] = res["distance"] / st["ray_n"] * res["convergent_mask"].float()  # raytracer.py:393,552
+        res.update({"ray_o": st["ray_o"], "ray_d": st["ray_d"]})
+        st["res"] = res
+        return st
+
+    def trace_records(self, st) -> torch.Tensor:
+        return _pack(st["res"], TRACE_RECORD, st["V"] * st["n_r"])
+
+    @torch.no_grad()
+    def fill_holes(self, st, parts: Sequence[torch.Tensor]):
+        """parts[r] = rank r's trace records (all ranks, view-major).  Applies the reference's hole filling to each whole
+        view and takes this rank's pixels back out of the result."""
+        from .raytracer import fill_depth_holes
+        V, H, W, mine, n_r = st["V"], st["H"], st["W"], st["mine"], st["n_r"]
+        img = assemble_views(parts, st["lists"], V, H, W)
+        res = st["res"]
+        out = {k: [] for k in ("convergent_mask", "depth", "distance", "points")}
+        for v, cam in enumerate(st["cameras"]):
+            full = split_record(img[v], TRACE_RECORD)
+            full = {k: t.contiguous() for k, t in full.items()}
+            ro, rd, rn = cam.get_rays(cam.get_uv())
+            full.update({"ray_o": ro, "ray_d": rd, "ray_d_norm": rn})
+            fill_depth_holes(full)
+            for k in out:
+                out[k].append(full[k].reshape(H * W, -1)[mine])
+        res["convergent_mask"] = torch.cat(out["convergent_mask"]).reshape(-1)
+        res["depth"] = torch.cat(out["depth"]).reshape(-1)
+        res["distance"] = torch.cat(out["distance"]).reshape(-1)
+        res["points"] = torch.cat(out["points"]).reshape(-1, 3)
+        return st
+
+    @torch.no_grad()
+    def shade(self, st) -> torch.Tensor:
+        """Shade this rank's pixels (fused kernels when render_fn is the GGX one) and pack the per-pixel records."""
         from .raytracer import render_normal_and_color
-        render_normal_and_color(res, self.sdf_network, self.nets, self.render_fn, is_training=False)
-        # 4. pack + gather + un-tile
-        cols = []
-        for k, w in RECORD:
-            v = res[k]
-            v = v.float() if k == "convergent_mask" else v
-            cols.append(v.reshape(V * n_r, w))
-        local = torch.cat(cols, dim=1).contiguous()
-        sizes = [V * int(l.numel()) for l in lists]
+        render_normal_and_color(st["res"], self.sdf_network, self.nets, self.render_fn, is_training=False)
+        return _pack(st["res"], RECORD, st["V"] * st["n_r"])
+
+    @torch.no_grad()
+    def assemble(self, parts: Sequence[torch.Tensor], cameras, handle_edges: bool = False):
+        """Rank 0: un-tile the gathered records; with handle_edges the silhouette pass of render_camera on every view."""
+        from .raytracer import locate_silhouette, render_edge_pixels
+        H, W = cameras[0].H, cameras[0].W
+        lists = self._pix(H, W, cameras[0].device)[0]
+        img = assemble_views(parts, lists, len(cameras), H, W)
+        out = split_record(img)
+        if not handle_edges:
+            return out
+        out = {k: v.contiguous() for k, v in out.items()}
+        extra = {}
+        for v, cam in enumerate(cameras):
+            view = {k: t[v] for k, t in out.items()}
+            uv = cam.get_uv()
+            ro, rd, rn = cam.get_rays(uv)
+            view.update({"uv": uv, "ray_o": ro, "ray_d": rd, "ray_d_norm": rn})
+            locate_silhouette(view, cam, self.sdf_network, max_num_rays=self.chunk)
+            edge = view["edge_mask"]
+            for k in SHADE_KEYS:  # an edge pixel leaves the convergent mask BEFORE shading (raytracer.py:586): zeros
+                view[k][edge] = 0.0
+            if int(edge.sum()) > 0:
+                render_edge_pixels(view, cam, self.sdf_network, self.tracer, self.nets, self.render_fn, is_training=False)
+            for k in view:
+                if k not in out:
+                    extra.setdefault(k, []).append(view[k])
+            out["convergent_mask"][v] = view["convergent_mask"]
+        for k, vs in extra.items():
+            out[k] = vs if k.startswith("edge_") else torch.stack(vs)
+        return out
+
+    @torch.no_grad()
+    def render(self, cameras, collect_stats: bool = False, fill_holes: bool = False, handle_edges: bool = False):
+        st = self.trace_begin(cameras, collect_stats)
+        reduce_chunk_iters(st["chunk_iters"], self.group)
+        st = self.trace_finish(st)
+        sizes = [st["V"] * int(l.numel()) for l in st["lists"]]
+        if fill_holes:
+            st = self.fill_holes(st, all_gather_records(self.trace_records(st), sizes, self.group))
+        local = self.shade(st)
         parts = gather_records(local, sizes, self.group, dst=0)
         if parts is None:
             return None
-        img = assemble_views(parts, lists, V, H, W)
-        out = split_record(img)
+        return self.assemble(parts, cameras, handle_edges)
+
+
+@torch.no_grad()
+def render_emulated(world: int, cameras, sdf_network, color_network_dict, render_fn, raytracer_factory, tile: int = 32,
+                    chunk: int = 50000, fill_holes: bool = False, handle_edges: bool = False):
+    """The sharded render of `world` ranks played through on ONE device: `world` ShardedRenderer instances run their phase
+    methods one after the other and the exchanges (MAX of the chunk tables, all-gather, gather) are done in memory -- the
+    same code path as ShardedRenderer.render() minus torch.distributed.  Returns (result dict of rank 0, per-rank device
+    milliseconds of the rank-local phases): max_r of those is what an N-GPU step costs in kernels, their ratio to the
+    unsharded frame the strong-scaling factor load balance allows (tests/test_gpu_shards.py, bench.py)."""
+    rs = [ShardedRenderer(sdf_network, color_network_dict, raytracer_factory(), render_fn, tile=tile, chunk=chunk, world=world, rank=r)
+          for r in range(world)]
+    ms = [0.0] * world
+
+    def timed(r, fn, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a)
+        e1.record()
+        e1.synchronize()
+        ms[r] += e0.elapsed_time(e1)
         return out
+
+    sts = [timed(r, rs[r].trace_begin, cameras) for r in range(world)]
+    table = sts[0]["chunk_iters"].clone()
+    for st in sts[1:]:
+        table = torch.maximum(table, st["chunk_iters"])
+    for st in sts:
+        st["chunk_iters"].copy_(table)
+    sts = [timed(r, rs[r].trace_finish, sts[r]) for r in range(world)]
+    if fill_holes:
+        parts = [rs[r].trace_records(sts[r]) for r in range(world)]
+        sts = [timed(r, rs[r].fill_holes, sts[r], parts) for r in range(world)]
+    locals_ = [timed(r, rs[r].shade, sts[r]) for r in range(world)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = rs[0].assemble(locals_, cameras, handle_edges)
+    e1.record()
+    e1.synchronize()
+    return out, ms, e0.elapsed_time(e1)

@@ -48,6 +48,24 @@ def main():
                     print("MISMATCH view %d key %s: %d elements differ, max |d| %g" %
                           (v, k, int((a != b).sum()), float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())))
         print("SHARDED_CHECK", "OK" if ok else "FAIL", "world", world, "hits", int(out["convergent_mask"].sum()))
+    # the whole-image passes: hole filling on every rank (all-gather of the trace records), silhouette edges on rank 0
+    out2 = sh.render(cams, fill_holes=True, handle_edges=True)
+    if rank == 0:
+        import iron_amd.raytracer as rt
+        ok2 = True
+        for v, cam in enumerate(cams):
+            res = rt.raytrace_camera(cam, nets["sdf_network"], RayTracer(), max_num_rays=2000, fill_holes=True, detect_edges=True)
+            rt.render_normal_and_color(res, nets["sdf_network"], nets, fn)
+            if res["edge_mask"].sum() > 0:
+                rt.render_edge_pixels(res, cam, nets["sdf_network"], RayTracer(), nets, fn)
+            for k in ("convergent_mask", "distance", "points", "depth", "color", "normal", "diffuse_albedo", "specular_roughness",
+                      "edge_mask", "uv"):
+                a, b = out2[k][v].cpu().numpy(), res[k].cpu().numpy()
+                if not np.array_equal(a, b):
+                    ok2 = False
+                    print("MISMATCH (holes+edges) view %d key %s: %d elements differ" % (v, k, int((a != b).sum())))
+        print("SHARDED_EDGES_CHECK", "OK" if ok2 else "FAIL", "edge pixels", int(sum(int(m.sum()) for m in out2["edge_mask"])))
+        ok = ok and ok2
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0 and not ok:

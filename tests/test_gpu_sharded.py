@@ -21,6 +21,7 @@ def test_multi_rank_equals_single_process(world):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:]
+    assert "SHARDED_EDGES_CHECK OK" in r.stdout, r.stdout[-3000:]
 
 
 def test_world1_sharded_renderer_equals_render_camera():

@@ -32,8 +32,8 @@ def _worker(rank, world, port, H, W, tile, n_views, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from iron_amd.sharding import (RECORD_WIDTH, assemble_views, chunks_per_view, gather_records, global_ray_index,
-                                   reduce_chunk_iters, tile_pixels)
+    from iron_amd.sharding import (RECORD_WIDTH, TRACE_WIDTH, all_gather_records, assemble_views, chunks_per_view, gather_records,
+                                   global_ray_index, reduce_chunk_iters, tile_pixels)
     lists = [tile_pixels(H, W, tile, world, r) for r in range(world)]
     mine = lists[rank]
     chunk = 1000
@@ -47,6 +47,12 @@ def _worker(rank, world, port, H, W, tile, n_views, out_path):
     local_before = iters.clone()
     reduce_chunk_iters(iters)
     assert torch.all(iters >= local_before)
+    # exchange for fill_holes: every rank receives every rank's trace records and can assemble the whole image
+    tl = torch.cat([_record_of(mine, v, TRACE_WIDTH) for v in range(n_views)], dim=0)
+    everyone = all_gather_records(tl, [n_views * int(l.numel()) for l in lists])
+    full = assemble_views(everyone, lists, n_views, H, W)
+    for v in range(n_views):
+        assert torch.equal(full[v], _record_of(torch.arange(H * W), v, TRACE_WIDTH).reshape(H, W, TRACE_WIDTH))
     # exchange 2: gather + un-tile
     local = torch.cat([_record_of(mine, v, RECORD_WIDTH) for v in range(n_views)], dim=0)
     sizes = [n_views * int(l.numel()) for l in lists]
