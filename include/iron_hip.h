@@ -162,6 +162,19 @@ typedef struct iron_neus_composite_args {
     float* gradient_error_acc;     /* [2]: sum(relax * (|g|-1)^2), sum(relax); or NULL                   */
 } iron_neus_composite_args;
 int iron_neus_composite(const iron_neus_composite_args* args, void* stream);
+/* The same with the outside pass given as its ALPHA [n,mo] (what render_core itself takes, models/renderer.py:259-260,
+ * 312-321) instead of the NeRF density: args->bg_density / bg_dists are ignored, args->bg_color [n*mo,3] is the outside
+ * pass's sampled colour. */
+int iron_neus_composite_alpha(const iron_neus_composite_args* args, const float* background_alpha, void* stream);
+/* render_core_outside's compositing (models/renderer.py:174-187): density [n*mo] (the NeRF field's first output), dists
+ * [n,mo], sampled_color [n*mo,3], background_rgb [3] or NULL -> alpha [n,mo] = 1 - exp(-softplus(density) dists), weights
+ * [n,mo], color [n,3]. */
+int iron_neus_outside_composite(const float* density, const float* dists, const float* sampled_color, const float* background_rgb,
+                                int64_t n, int32_t mo, float* alpha, float* weights, float* color, void* stream);
+/* sample_pdf (models/renderer.py:45-75): bins [n,n_bins], weights [n,n_bins-1] -> samples [n,n_samples] by inverting the
+ * CDF of the piecewise-constant density at u [n,n_samples]; u == NULL is det=True (u = linspace(0.5/k, 1-0.5/k, k)). */
+int iron_neus_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n, int32_t n_bins, int32_t n_samples,
+                         float* samples, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise geometry
@@ -181,6 +194,9 @@ int iron_ggx_colocated(float light, const float* distance, const float* normal, 
                        const float* diffuse_albedo, const float* specular_albedo, const float* roughness,
                        const float* tab_trans, const float* tab_diff_trans, int64_t n, float* diffuse_rgb,
                        float* specular_rgb, float* rgb, void* stream);
+
+/* smithG1 (models/renderer_ggx.py:12-16) on its own: cos_theta, alpha, out all [n]. */
+int iron_smith_g1(const float* cos_theta, const float* alpha, int64_t n, float* out, void* stream);
 
 /* SURVEY 8 row f-4 -- the fork's other co-located heads.
  * CompositeRenderer.forward (models/renderer_ggx.py:781-858), quirks included: the GGX NDF is evaluated with
@@ -218,6 +234,13 @@ int iron_coloc_head(int32_t kind, float light, float eta, float k, const float* 
  * semantics and are parity-unpinned. */
 int iron_morph_closing3x3(const float* depth, int32_t H, int32_t W, float* tmp, float* out, void* stream);
 int iron_sobel_magnitude(const float* depth, int32_t H, int32_t W, float* out, void* stream);
+
+/* Tail of locate_edge_points (models/raytracer.py:481-500) in one launch: points [n,3] are projected like Camera.project
+ * (w2c16 = W2C, k16 = K, both 4x4 row-major HOST floats) into uv [n,2]; for every point with found[i] != 0 whose pixel index
+ * floor(v) * W + floor(u) lies in [0, H*W) the pixel's entry of first [H*W] (int32, pre-set by the caller to INT32_MAX) is
+ * lowered to i: afterwards first[p] is the first found candidate of pixel p -- the one unique() keeps -- or INT32_MAX. */
+int iron_edge_pixels(const float* points, const uint8_t* found, int64_t n, const float* w2c16, const float* k16, int32_t H, int32_t W,
+                     float* uv, int32_t* first, void* stream);
 
 /* The fill_holes update of raytrace_camera (models/raytracer.py:558-564) on the device: where the closed depth image
  * `depth_closed` (iron_morph_closing3x3) makes a hit of a non-convergent pixel, the reference rewrites depth at those

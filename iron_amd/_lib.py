@@ -106,10 +106,15 @@ SYMBOLS = {
     "iron_neus_mid_points": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P, _P, _P, _P]),
     "iron_neus_need_background": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
     "iron_neus_composite": (C.c_int, [C.POINTER(iron_neus_composite_args), _P]),
+    "iron_neus_composite_alpha": (C.c_int, [C.POINTER(iron_neus_composite_args), _P, _P]),
+    "iron_neus_outside_composite": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "iron_neus_sample_pdf": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "iron_smith_g1": (C.c_int, [_P, _P, _I64, _P, _P]),
     "iron_nerf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "iron_edge_walk": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _P, _P, _P]),
     "iron_morph_closing3x3": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "iron_sobel_magnitude": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "iron_edge_pixels": (C.c_int, [_P, _P, _I64, C.POINTER(_F), C.POINTER(_F), _I32, _I32, _P, _P, _P]),
     "iron_fill_holes": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "iron_edge_sides": (C.c_int, [_P, _P, C.POINTER(_F), _I64, _P, _P, _P]),
     "iron_edge_blend": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),

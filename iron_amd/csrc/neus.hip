@@ -176,6 +176,7 @@ struct NeusCompositeArgs {
     const float *dists, *pts, *dirs, *sdf, *grad, *color;  // [n*m], [n*m,3], [n*m,3], [n*m], [n*m,3], [n*m,3]
     const float *bg_dists, *bg_density, *bg_color;          // outside: [n*mo], [n*mo], [n*mo,3] or null
     const float* background_rgb;                            // [3] or null
+    const float* bg_alpha;                                  // [n*mo] or null: the outside pass's alpha given directly (render_core's own signature)
     int n, m, mo;
     float inv_s, cos_anneal;
     float *out_color, *weights, *cdf, *inside, *weight_sum, *weight_max, *gerr_acc;  // gerr_acc[2]: sum relax*err, sum relax
@@ -186,12 +187,15 @@ __global__ void k_neus_composite(NeusCompositeArgs a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float e_sum = 0.0f, e_cnt = 0.0f;
     if (r < a.n) {
-        const int mt = a.bg_density ? a.mo : a.m;  // total samples of the composited row
+        const bool has_bg = a.bg_density || a.bg_alpha;
+        const int mt = has_bg ? a.mo : a.m;  // total samples of the composited row
         float trans = 1.0f, wsum = 0.0f, wmax = 0.0f, col[3] = {0.f, 0.f, 0.f};
         for (int j = 0; j < mt; ++j) {
             float alpha = 0.0f, c[3] = {0.f, 0.f, 0.f};
             float bg_alpha = 0.0f;
-            if (a.bg_density) {
+            if (a.bg_alpha) {
+                bg_alpha = a.bg_alpha[(size_t)r * a.mo + j];
+            } else if (a.bg_density) {
                 const size_t q = (size_t)r * a.mo + j;
                 bg_alpha = 1.0f - expf(-softplusf_(a.bg_density[q]) * a.bg_dists[q]);
             }
@@ -214,7 +218,7 @@ __global__ void k_neus_composite(NeusCompositeArgs a) {
                 e_cnt += relax;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) c[k] = a.color[3 * q + k];
-                if (a.bg_density) {
+                if (has_bg) {
                     const size_t qb = (size_t)r * a.mo + j;
                     alpha = alpha * inside + bg_alpha * (1.0f - inside);
 #pragma unroll
@@ -252,6 +256,65 @@ __global__ void k_neus_composite(NeusCompositeArgs a) {
     if ((threadIdx.x & 63) == 0 && a.gerr_acc) {
         atomicAdd(&a.gerr_acc[0], e_sum);
         atomicAdd(&a.gerr_acc[1], e_cnt);
+    }
+}
+
+// render_core_outside, compositing half (renderer.py:174-187): alpha = 1 - exp(-softplus(density) * dists), transmittance
+// scan, colour; one thread per ray
+__global__ void k_neus_outside_composite(const float* __restrict__ density, const float* __restrict__ dists, const float* __restrict__ rgb,
+                                         const float* __restrict__ background_rgb, int n, int mo, float* __restrict__ alpha_out,
+                                         float* __restrict__ weights, float* __restrict__ color) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float trans = 1.0f, wsum = 0.0f, col[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < mo; ++j) {
+        const size_t q = (size_t)r * mo + j;
+        const float alpha = 1.0f - expf(-softplusf_(density[q]) * dists[q]);
+        const float w = alpha * trans;
+        trans = trans * (1.0f - alpha + 1e-7f);
+        alpha_out[q] = alpha;
+        weights[q] = w;
+        wsum += w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] += rgb[3 * q + k] * w;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) color[3 * (size_t)r + k] = col[k] + (background_rgb ? background_rgb[k] * (1.0f - wsum) : 0.0f);
+}
+
+// sample_pdf (renderer.py:45-75): inverse-CDF samples of a piecewise-constant density.  bins [n,mb], weights [n,mb-1];
+// u [n,k] uniform numbers, or null for det=True (u = linspace(0.5/k, 1 - 0.5/k, k)).  One thread per row.
+__global__ void k_neus_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights, const float* __restrict__ u_in,
+                                  int n, int mb, int k_samples, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* b = bins + (size_t)r * mb;
+    const float* w = weights + (size_t)r * (mb - 1);
+    float cdf[kMaxSamples];
+    float wsum = 0.0f;
+    for (int j = 0; j < mb - 1; ++j) wsum += w[j] + 1e-5f;
+    cdf[0] = 0.0f;
+    float acc = 0.0f;
+    for (int j = 0; j < mb - 1; ++j) {
+        acc += (w[j] + 1e-5f) / wsum;
+        cdf[j + 1] = acc;
+    }
+    const float start = 0.5f / k_samples, end = 1.0f - 0.5f / k_samples;
+    const float step = k_samples > 1 ? (end - start) / (float)(k_samples - 1) : 0.0f;
+    for (int k = 0; k < k_samples; ++k) {
+        const float u = u_in ? u_in[(size_t)r * k_samples + k]
+                             : (k_samples == 1 ? start : (k < k_samples / 2 ? start + step * k : end - step * (k_samples - 1 - k)));
+        int lo = 0, hi = mb;  // searchsorted(cdf, u, right=True): first index with cdf > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < mb - 1 ? lo : mb - 1;
+        float denom = cdf[above] - cdf[below];
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - cdf[below]) / denom;
+        out[(size_t)r * k_samples + k] = b[below] + t * (b[above] - b[below]);
     }
 }
 
@@ -337,14 +400,47 @@ extern "C" int iron_neus_need_background(const float* pts, int64_t n, int32_t m,
     return IRON_OK;
 }
 
-extern "C" int iron_neus_composite(const iron_neus_composite_args* p, void* stream) {
+static int neus_composite_launch(const iron_neus_composite_args* p, const float* bg_alpha, void* stream);
+
+extern "C" int iron_neus_composite(const iron_neus_composite_args* p, void* stream) { return neus_composite_launch(p, nullptr, stream); }
+
+extern "C" int iron_neus_composite_alpha(const iron_neus_composite_args* p, const float* background_alpha, void* stream) {
+    if (!background_alpha) return IRON_ERR_BAD_ARG;
+    return neus_composite_launch(p, background_alpha, stream);
+}
+
+extern "C" int iron_neus_outside_composite(const float* density, const float* dists, const float* sampled_color, const float* background_rgb,
+                                           int64_t n, int32_t mo, float* alpha, float* weights, float* color, void* stream) {
+    if (n < 0 || mo < 1) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!density || !dists || !sampled_color || !alpha || !weights || !color) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_neus_outside_composite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, density, dists, sampled_color,
+                       background_rgb, (int)n, mo, alpha, weights, color);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_neus_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n, int32_t n_bins, int32_t n_samples,
+                                    float* samples, void* stream) {
+    if (n < 0 || n_bins < 2 || n_bins > kMaxSamples || n_samples < 1) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!bins || !weights || !samples) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_neus_sample_pdf, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, bins, weights, u, (int)n, n_bins,
+                       n_samples, samples);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+static int neus_composite_launch(const iron_neus_composite_args* p, const float* bg_alpha, void* stream) {
     if (!p || p->n < 0 || p->m < 1 || p->m > kMaxSamples) return IRON_ERR_BAD_ARG;
     if (p->n == 0) return IRON_OK;
     if (!p->dists || !p->pts || !p->dirs || !p->sdf || !p->grad || !p->color || !p->out_color || !p->weights || !p->weight_sum ||
         !p->weight_max)
         return IRON_ERR_BAD_ARG;
     if (p->bg_density && (!p->bg_dists || !p->bg_color || p->mo < p->m || p->mo > kMaxSamples)) return IRON_ERR_BAD_ARG;
+    if (bg_alpha && (!p->bg_color || p->mo < p->m || p->mo > kMaxSamples)) return IRON_ERR_BAD_ARG;
     NeusCompositeArgs a;
+    a.bg_alpha = bg_alpha;
     a.dists = p->dists; a.pts = p->pts; a.dirs = p->dirs; a.sdf = p->sdf; a.grad = p->grad; a.color = p->color;
     a.bg_dists = p->bg_dists; a.bg_density = p->bg_density; a.bg_color = p->bg_color; a.background_rgb = p->background_rgb;
     a.n = (int)p->n; a.m = p->m; a.mo = p->mo; a.inv_s = p->inv_s; a.cos_anneal = p->cos_anneal_ratio;

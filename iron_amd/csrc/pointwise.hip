@@ -245,6 +245,41 @@ __global__ void k_edge_blend(const float* __restrict__ side_color /*[2n,3]*/, co
     }
 }
 
+struct Mat44x2 {
+    float w2c[16];
+    float k[16];
+};
+
+// Tail of locate_edge_points (models/raytracer.py:481-500): project the found points (Camera.project: p_h . W2C^T . K^T, then
+// the perspective division), take the pixel they fall in, and keep for every pixel the FIRST found point in candidate order
+// (what unique() / scatter_ of the reversed permutation select): first[pixel] = min candidate index, by atomicMin.
+// The pixel index is y * W + x and only IT is range-checked, as in the reference (:489-490).
+__global__ void k_edge_project_first(const float* __restrict__ points, const uint8_t* __restrict__ found, int64_t n, Mat44x2 m, int H, int W,
+                                     float* __restrict__ uv, int* __restrict__ first) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
+        float c[4], q[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = fmaf(1.0f, m.w2c[4 * r + 3], fmaf(z, m.w2c[4 * r + 2], fmaf(y, m.w2c[4 * r + 1], x * m.w2c[4 * r])));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) q[r] = fmaf(c[3], m.k[4 * r + 3], fmaf(c[2], m.k[4 * r + 2], fmaf(c[1], m.k[4 * r + 1], c[0] * m.k[4 * r])));
+        const float u = q[0] / q[2], v = q[1] / q[2];
+        uv[2 * i] = u;
+        uv[2 * i + 1] = v;
+        if (!found[i]) continue;
+        const long long pix = (long long)floorf(v) * (long long)W + (long long)floorf(u);
+        if (pix < 0 || pix >= (long long)H * W) continue;
+        atomicMin(&first[pix], (int)i);
+    }
+}
+
+// smithG1 (models/renderer_ggx.py:12-16) as a standalone operator
+__global__ void k_smith_g1(const float* __restrict__ cos_theta, const float* __restrict__ alpha, int64_t n, float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = smith_g1(cos_theta[i], alpha[i]);
+}
+
 static inline int pw_grid(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -384,6 +419,29 @@ extern "C" int iron_edge_blend(const float* side_color, const float* pos_weight,
         return IRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_edge_blend, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, side_color, pos_weight, edge_grad, edge_uv,
                        edge_points, pixel_idx, n, n_pixels, color, normal, uv, points);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_smith_g1(const float* cos_theta, const float* alpha, int64_t n, float* out, void* stream) {
+    if (n < 0) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!cos_theta || !alpha || !out) return IRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_smith_g1, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, cos_theta, alpha, n, out);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_edge_pixels(const float* points, const uint8_t* found, int64_t n, const float* w2c16, const float* k16, int32_t H, int32_t W,
+                                float* uv, int32_t* first, void* stream) {
+    if (n < 0 || H < 0 || W < 0 || !w2c16 || !k16) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!points || !found || !uv || !first) return IRON_ERR_BAD_ARG;
+    Mat44x2 m;
+    for (int i = 0; i < 16; ++i) { m.w2c[i] = w2c16[i]; m.k[i] = k16[i]; }
+    hipLaunchKernelGGL(k_edge_project_first, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, points, found, n, m, (int)H, (int)W, uv,
+                       (int*)first);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

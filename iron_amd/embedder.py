@@ -10,24 +10,35 @@ import torch
 
 
 class Embedder:
-    """models/embedder.py:6-36: cat[x, sin(x*2^0), cos(x*2^0), ..., sin(x*2^(L-1)), cos(x*2^(L-1))]."""
+    """models/embedder.py:6-36, configured by the same keyword dictionary (include_input, input_dims, max_freq_log2,
+    num_freqs, log_sampling, periodic_fns): cat[x, p(x f_0) for p in periodic_fns, ..., p(x f_{N-1})] with f_i spaced in log2
+    (log_sampling) or linearly between 1 and 2^max_freq_log2."""
 
-    def __init__(self, input_dims: int, num_freqs: int, include_input: bool = True):
-        self.input_dims = input_dims
-        self.num_freqs = num_freqs
-        self.include_input = include_input
-        self.freq_bands = 2.0 ** torch.linspace(0.0, float(num_freqs - 1), num_freqs)
-        self.out_dim = (input_dims if include_input else 0) + 2 * input_dims * num_freqs
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.create_embedding_fn()
+
+    def create_embedding_fn(self):
+        cfg = self.kwargs
+        n_freqs, top = cfg["num_freqs"], cfg["max_freq_log2"]
+        if cfg["log_sampling"]:
+            self.freq_bands = 2.0 ** torch.linspace(0.0, top, n_freqs)
+        else:
+            self.freq_bands = torch.linspace(2.0 ** 0.0, 2.0 ** top, n_freqs)
+        self.periodic_fns = list(cfg["periodic_fns"])
+        self.include_input = bool(cfg["include_input"])
+        width = cfg["input_dims"]
+        self.out_dim = (width if self.include_input else 0) + width * n_freqs * len(self.periodic_fns)
 
     def embed(self, inputs: torch.Tensor) -> torch.Tensor:
         parts = [inputs] if self.include_input else []
         for freq in self.freq_bands:
-            parts.append(torch.sin(inputs * freq))
-            parts.append(torch.cos(inputs * freq))
+            parts.extend(fn(inputs * freq) for fn in self.periodic_fns)
         return torch.cat(parts, -1)
 
 
-def get_embedder(multires: int, input_dims: int = 3):
-    """models/embedder.py:39-54: returns (embed_fn, out_dim)."""
-    obj = Embedder(input_dims=input_dims, num_freqs=multires)
+def get_embedder(multires, input_dims=3):
+    """models/embedder.py:39-54: returns (embed_fn, out_dim) of the NeRF encoding with `multires` octaves."""
+    obj = Embedder(include_input=True, input_dims=input_dims, max_freq_log2=multires - 1, num_freqs=multires, log_sampling=True,
+                   periodic_fns=[torch.sin, torch.cos])
     return (lambda x, eo=obj: eo.embed(x)), obj.out_dim

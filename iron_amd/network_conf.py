@@ -55,7 +55,7 @@ def comp_env_light_network() -> RenderingNetwork:
                             mode="points_only", squeeze_out=False, output_bias=0.0, output_scale=1.0)
 
 
-def init_rendering_network_dict(renderer_name="ggx", device="cuda"):
+def init_rendering_network_dict(renderer_name="comp", device="cuda"):
     """models/network_conf.py:47-122 (`ggx`) and :318-447 (`comp2`; `comp`, which render_surface.py:107 asks for, is not
     defined by the reference's factory and is served by the same shapes).  color_network of the comp2 dict (the
     stage-1 colour net, unused by the render path) is not built."""
@@ -79,7 +79,7 @@ def init_rendering_network_dict(renderer_name="ggx", device="cuda"):
     }
 
 
-def choose_renderer(renderer_name="ggx"):
+def choose_renderer(renderer_name="comp"):
     """models/network_conf.py:748-764."""
     from .renderer_ggx import CompositeRenderer, GGXColocatedRenderer
 

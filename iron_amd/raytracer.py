@@ -229,6 +229,8 @@ class Camera(object):
         self._kinv_host = (C.c_float * 9)(*self.K_inv[:3, :3].cpu().reshape(-1).tolist())
         self._c2w_host = (C.c_float * 12)(*self.C2W[:3, :4].cpu().reshape(-1).tolist())
         self._w2c_rot_host = (C.c_float * 9)(*W2C.detach().float()[:3, :3].cpu().reshape(-1).tolist())
+        self._w2c_host16 = (C.c_float * 16)(*W2C.detach().float().cpu().reshape(-1).tolist())
+        self._k_host16 = (C.c_float * 16)(*K.detach().float().cpu().reshape(-1).tolist())
 
     def get_rays(self, uv):
         """uv [..., 2] -> ray_o [...,3], ray_d [...,3] (unit), ray_d_norm [...] (raytracer.py:254-286)."""
@@ -409,23 +411,25 @@ def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_si
                 walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
                 walk = walk - sdf * nrm
                 cur = torch.where(found.unsqueeze(-1), cur, cur + step_size * walk)
-    edge_points = cur[found]
-    edge_mask = camera.get_uv().new_zeros(camera.H, camera.W).bool()
-    edge_uv = torch.zeros_like(edge_points[..., :2])
-    update_pixels = torch.zeros(0, dtype=torch.long, device=dev)
-    if edge_points.shape[0] > 0:
-        edge_uv = camera.project(edge_points)
-        update_pixels = torch.floor(edge_uv.detach()).long()
-        update_pixels = update_pixels[:, 1] * camera.W + update_pixels[:, 0]
-        ok = (update_pixels < camera.H * camera.W) & (update_pixels >= 0)
-        update_pixels, edge_points, edge_uv = update_pixels[ok], edge_points[ok], edge_uv[ok]
-        if update_pixels.shape[0] > 0:
-            cnt = update_pixels.shape[0]
-            update_pixels, uidx = unique(update_pixels, dim=0)
-            uidx = torch.arange(cnt, device=dev)[uidx]
-            edge_points = edge_points[uidx]
-            edge_uv = edge_uv[uidx]
-            edge_mask.view(-1)[update_pixels] = True
+    # one edge point per pixel: the first found candidate that projects into it (raytracer.py:481-500), iron_edge_pixels
+    n_cand = cur.shape[0]
+    n_pix = camera.H * camera.W
+    first = torch.full((n_pix,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+    if n_cand > 0:
+        cur = cur.contiguous()
+        uv_all = torch.empty((n_cand, 2), dtype=torch.float32, device=dev)
+        flags = found.contiguous().view(torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().iron_edge_pixels(cur.data_ptr(), flags.data_ptr(), n_cand, camera._w2c_host16, camera._k_host16, camera.H,
+                                                    camera.W, uv_all.data_ptr(), first.data_ptr(), _lib.stream_ptr(dev)))
+    edge_mask = (first != 2 ** 31 - 1).reshape(camera.H, camera.W)
+    update_pixels = edge_mask.reshape(-1).nonzero().reshape(-1)          # ascending: the order torch.unique returns
+    if update_pixels.shape[0] > 0:
+        winner = first[update_pixels].long()
+        edge_points, edge_uv = cur[winner], uv_all[winner]
+    else:
+        edge_points = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+        edge_uv = torch.zeros((0, 2), dtype=torch.float32, device=dev)
     return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
 
 

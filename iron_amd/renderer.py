@@ -54,6 +54,43 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return _lib.require_cuda_f32(t.detach(), name).contiguous()
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """models/renderer.py:45-75: n_samples depths per row drawn from the piecewise-constant density `weights` (+1e-5) over
+    `bins` by inverting its CDF -- at the regular positions linspace(0.5/n, 1-0.5/n) when det, else at uniform random numbers
+    (torch's generator of the device; the reference draws them on its default device).  bins [n,m], weights [n,m-1]."""
+    b, w = _f32(bins, "bins"), _f32(weights, "weights")
+    if b.dim() != 2 or w.shape != (b.shape[0], b.shape[1] - 1):
+        raise _lib.IronError("sample_pdf expects bins [n,m] and weights [n,m-1]")
+    n = b.shape[0]
+    u = None if det else torch.rand((n, int(n_samples)), dtype=torch.float32, device=b.device)
+    out = torch.empty((n, int(n_samples)), dtype=torch.float32, device=b.device)
+    with torch.cuda.device(b.device):
+        _lib.check(_lib.load().iron_neus_sample_pdf(b.data_ptr(), w.data_ptr(), _lib.ptr(u), n, b.shape[1], int(n_samples), out.data_ptr(),
+                                                    _lib.stream_ptr(b.device)))
+    return out
+
+
+class NeRFRenderer:
+    """models/renderer.py:78-126: constructor and attributes as in the reference.  Its render() unpacks `sampled_color,
+    density = self.nerf(pts, dirs)` -- the return order of tcnn_fields.TCNNNeRF (tiny-cuda-nn, a third-party CUDA library
+    that is neither vendored in the reference nor installable here); with models.fields.NeRF, which returns (alpha, rgb), that
+    line mis-shapes in the reference as well.  The only caller is render_volume_tcnn.py.  Out of this build's scope:
+    render() says so instead of computing something unpinned."""
+
+    def __init__(self, nerf, n_samples, n_importance, n_outside, up_sample_steps, perturb):
+        self.nerf = nerf
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+
+    def render(self, rays_o, rays_d, near, far, background_dist=0, sample_dist=0.01, background_rgb=None, cos_anneal_ratio=None):
+        raise _lib.IronError("NeRFRenderer.render belongs to the tiny-cuda-nn experiment of render_volume_tcnn.py (its nerf must return "
+                             "(colour, density) like tcnn_fields.TCNNNeRF); not part of the sphere-trace / NeuS path built here -- use "
+                             "NeuSRenderer.render, whose background pass is this field evaluated by iron_nerf_forward")
+
+
 class NeuSRenderer:
     """models/renderer.py:128-149 (same constructor arguments, same attribute names)."""
 
@@ -145,6 +182,78 @@ class NeuSRenderer:
         """renderer.py:455-462."""
         return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
                                 query_func=lambda pts: -self.sdf_network.sdf(pts))
+
+    # ---- the two cores under their own names (models/renderer.py:151-187, 250-344) ---------------------------------
+    def _refuse_training(self, what, *nets):
+        from .autograd import any_requires_grad
+        params = [p for net in nets if net is not None for p in net.parameters()]
+        if torch.is_grad_enabled() and any_requires_grad(*params):
+            raise _lib.IronError("%s on its own is inference-only; NeuSRenderer.render() attaches both cores to the parameters "
+                                 "(iron_amd.autograd) -- call it, or wrap this call in torch.no_grad()" % what)
+
+    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None):
+        """models/renderer.py:151-187: the NeRF++ background pass on its own -> color, sampled_color, alpha, weights."""
+        self._refuse_training("render_core_outside", nerf)
+        rays_o, rays_d, z_vals = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z_vals, "z_vals")
+        n, mo = z_vals.shape
+        dev = z_vals.device
+        with torch.no_grad(), torch.cuda.device(dev):
+            dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, True)
+            density, rgb = nerf(pts, dirs)
+            density, rgb = density.reshape(-1).contiguous(), rgb.contiguous()
+            alpha, weights = torch.empty_like(dists), torch.empty_like(dists)
+            color = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            bg = None if background_rgb is None else _f32(background_rgb, "background_rgb").reshape(-1)
+            _lib.check(_lib.load().iron_neus_outside_composite(density.data_ptr(), dists.data_ptr(), rgb.data_ptr(), _lib.ptr(bg), n, mo,
+                                                               alpha.data_ptr(), weights.data_ptr(), color.data_ptr(), _lib.stream_ptr(dev)))
+        return {"color": color, "sampled_color": rgb.reshape(n, mo, 3), "alpha": alpha, "weights": weights}
+
+    def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network, background_alpha=None,
+                    background_sampled_color=None, background_rgb=None, cos_anneal_ratio=0.0):
+        """models/renderer.py:250-344 under its own name and signature (render() fuses it with the background pass):
+        section mid points, get_all, colour network, logistic-CDF alpha, blend with the outside pass's alpha / colour,
+        transmittance scan -> the reference's dict (color, sdf, dists, gradients, s_val, mid_z_vals, weights, cdf,
+        gradient_error, inside_sphere)."""
+        self._refuse_training("render_core", sdf_network, deviation_network, color_network)
+        rays_o, rays_d, z_vals = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z_vals, "z_vals")
+        n, m = z_vals.shape
+        dev = z_vals.device
+        lib = _lib.load()
+        with torch.no_grad(), torch.cuda.device(dev):
+            dists, pts, dirs = self._mid_points(rays_o, rays_d, z_vals, sample_dist, False)
+            sdf, feat, grad = sdf_network.get_all(pts, is_training=False)
+            color_in = color_network(pts, grad, dirs, feat).contiguous()
+            inv_s = float(deviation_network(torch.zeros([1, 3], device=dev))[0, 0].clip(1e-6, 1e6))
+            mo = m
+            bg_alpha = bg_color = None
+            if background_alpha is not None:
+                bg_alpha = _f32(background_alpha, "background_alpha")
+                mo = bg_alpha.shape[1]
+                bg_color = _f32(background_sampled_color, "background_sampled_color").reshape(n * mo, 3)
+            a = _lib.iron_neus_composite_args()
+            sdf_c, grad_c = sdf.reshape(-1).contiguous(), grad.contiguous()
+            weights = torch.empty((n, mo), dtype=torch.float32, device=dev)
+            cdf, inside = torch.empty((n, m), dtype=torch.float32, device=dev), torch.empty((n, m), dtype=torch.float32, device=dev)
+            out_color = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            wsum, wmax = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+            gerr = torch.zeros(2, dtype=torch.float32, device=dev)
+            bg = None if background_rgb is None else _f32(background_rgb, "background_rgb").reshape(-1)
+            a.dists, a.pts, a.dirs, a.sdf, a.grad, a.color = (dists.data_ptr(), pts.data_ptr(), dirs.data_ptr(), sdf_c.data_ptr(),
+                                                              grad_c.data_ptr(), color_in.data_ptr())
+            a.bg_dists = a.bg_density = None
+            a.bg_color = _lib.ptr(bg_color)
+            a.background_rgb = _lib.ptr(bg)
+            a.n, a.m, a.mo, a.inv_s, a.cos_anneal_ratio = n, m, mo, inv_s, float(cos_anneal_ratio)
+            a.out_color, a.weights, a.cdf, a.inside_sphere = out_color.data_ptr(), weights.data_ptr(), cdf.data_ptr(), inside.data_ptr()
+            a.weight_sum, a.weight_max, a.gradient_error_acc = wsum.data_ptr(), wmax.data_ptr(), gerr.data_ptr()
+            if bg_alpha is not None:
+                _lib.check(lib.iron_neus_composite_alpha(C.byref(a), bg_alpha.data_ptr(), _lib.stream_ptr(dev)))
+            else:
+                _lib.check(lib.iron_neus_composite(C.byref(a), _lib.stream_ptr(dev)))
+            mid_z = z_vals + dists * 0.5
+        return {"color": out_color, "sdf": sdf.reshape(-1, 1), "dists": dists, "gradients": grad.reshape(n, m, 3),
+                "s_val": torch.full((n * m, 1), 1.0 / inv_s, dtype=torch.float32, device=dev), "mid_z_vals": mid_z, "weights": weights,
+                "cdf": cdf, "gradient_error": gerr[0] / (gerr[1] + 1e-5), "inside_sphere": inside}
 
     # ---- render ---------------------------------------------------------------------------------------------------
     def _trainable(self) -> bool:

@@ -28,6 +28,20 @@ def load_mts_tables():
     return torch.from_numpy(z["ext_rtrans"].astype(np.float32)), torch.from_numpy(z["int_diff_rtrans"].astype(np.float32))
 
 
+def smithG1(cosTheta, alpha):
+    """models/renderer_ggx.py:12-16: Smith shadowing term 2 / (1 + hypot(alpha tan(theta), 1)) of the GGX lobe, as a
+    standalone operator (the renderers evaluate it inside their fused kernels).  Inputs broadcast like the reference's
+    tensor expression; CUDA fp32 only, no autograd (the differentiable form lives inside GGXColocatedFn)."""
+    if torch.is_grad_enabled() and (getattr(cosTheta, "requires_grad", False) or getattr(alpha, "requires_grad", False)):
+        raise _lib.IronError("smithG1 as a standalone operator is inference-only; train through GGXColocatedRenderer / CompositeRenderer")
+    c, a = torch.broadcast_tensors(_lib.require_cuda_f32(cosTheta, "cosTheta"), _lib.require_cuda_f32(alpha, "alpha"))
+    c, a = c.contiguous(), a.contiguous()
+    out = torch.empty_like(c)
+    with torch.cuda.device(c.device):
+        _lib.check(_lib.load().iron_smith_g1(c.data_ptr(), a.data_ptr(), c.numel(), out.data_ptr(), _lib.stream_ptr(c.device)))
+    return out
+
+
 class GGXColocatedRenderer(nn.Module):
     def __init__(self, use_cuda=False):
         super().__init__()

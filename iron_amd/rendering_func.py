@@ -55,6 +55,41 @@ def get_materials_multi(color_network_dict, points, normals, features, is_metal=
             "material_vector": color_network_dict["material_network"](points, None, None, features).abs()}
 
 
+class MaterialPredictor(torch.nn.Module):
+    """render_surface.py:434-450: surface points -> (diffuse_albedo [n,3], specular_albedo [n,3], specular_roughness [n,1]),
+    the callable export_materials (models/export_materials.py:165-203) samples 25 M times to splat its 2048^2 textures.
+    get_all (value + analytic normal, one launch) -> normalise -> the material networks of the dictionary at hand: the
+    composite set (get_materials_comp, what the reference's class hard-codes) when the dictionary has it, the ggx set
+    (get_materials) otherwise."""
+
+    def __init__(self, sdf_network, color_network_dict):
+        super().__init__()
+        self.sdf_network = sdf_network
+        self.color_network_dict = color_network_dict
+
+    @torch.no_grad()
+    def forward(self, points):
+        _, features, normals = self.sdf_network.get_all(points, is_training=False)
+        normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+        fn = get_materials_comp if "metallic_network" in self.color_network_dict else get_materials
+        res = fn(self.color_network_dict, points, normals, features)
+        return res["diffuse_albedo"], res["specular_albedo"], res["specular_roughness"]
+
+
+@torch.no_grad()
+def query_materials(material_predictor, points, max_num_pts=320000):
+    """The bulk query loop of export_materials (models/export_materials.py:181-191): `points` [N,3] in splits of max_num_pts
+    -> [N,7] = cat(diffuse_albedo, specular_albedo, specular_roughness), kept on the device (the reference moves every split
+    to the host; the splat that follows is host-side numpy there and is not part of this build)."""
+    pts = _lib.require_cuda_f32(points, "points").reshape(-1, 3)
+    out = torch.empty((pts.shape[0], 7), dtype=torch.float32, device=pts.device)
+    for start in range(0, pts.shape[0], int(max_num_pts)):
+        kd, ks, rough = material_predictor(pts[start:start + int(max_num_pts)])
+        rows = out[start:start + kd.shape[0]]
+        rows[:, 0:3], rows[:, 3:6], rows[:, 6:7] = kd, ks, rough.reshape(-1, 1)
+    return out
+
+
 class CompRenderFn:
     """render_surface.py:159-234 (render_fn_comp) as a callable: get_materials_comp -> CompositeRenderer -> scatter.
     Every step runs through its HIP operator (8 material-network launches + one composite kernel); scalar maps keep

@@ -116,7 +116,7 @@ def edges():
     print("G15 loss", loss.item(), "edge pixels", int(res["edge_mask"].sum()), "param tensors", n_params)
 
 
-if __name__ == "__main__" and not ({"--floor", "--c3"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--floor", "--c3", "--stable"} & set(sys.argv)):
     if "--edges" in sys.argv:
         edges()
     else:
@@ -255,3 +255,140 @@ if __name__ == "__main__" and "--floor" in sys.argv:
     floor_g15()
 if __name__ == "__main__" and "--c3" in sys.argv:
     c3(int(sys.argv[sys.argv.index("--c3") + 1]) if len(sys.argv) > sys.argv.index("--c3") + 1 else 512)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# G15s: the G15 setting with the ill-conditioned edge pixels taken out of the loss.  reparam_points divides by
+# clamp(n . (-d), 1e-4) (raytracer.py:17-24): a side ray that grazes the surface enters the gradient with a factor of up to
+# 1e4 and its hit point is only defined to sdf_threshold / (n . d) along the ray, so a handful of such pixels decide how well
+# ANY two runs agree (the reference's own fp32 and fp64 runs included).  The pixels whose side rays hit with
+# |n . d| < GRAZING are found here, by the reference's own tracer on the reference's own side samples, and stored as an
+# INPUT mask; fp32 and fp64 gradients of the masked loss are the golden values.
+# ----------------------------------------------------------------------------------------------------------------------
+GRAZING = 0.1
+# ... and the blend weight 1 - (a - sin a) / 2pi, a = 2 acos(x), x = clamp(h / 0.707, 0, 1) (raytracer.py:696-698) has the
+# derivative -2 / sqrt(1 - x^2) in x: unbounded as the edge point approaches the rim of the pixel disc, and with a relative
+# sensitivity x / (1 - x^2) to the position itself -- 1e-5 px of walk rounding is 1e-3 of gradient at x = 0.995.  Pixels with
+# x > RIM are taken out as well, and so are pixels whose edge point the reference's own fp32 and fp64 walks place more than
+# WALK_TOL apart (the 16-step walk amplifies rounding; such a pixel is not defined to better than that by the reference).
+RIM = 0.95
+WALK_TOL = 1e-5
+# ... and clamp(x, 0, 1) passes gradient for x >= 0 and none for x < 0 (torch.clamp's backward).  A candidate that already
+# satisfies |n.v| <= 0.05 is "found" without walking, so its edge point is the pixel's own hit point and projects onto the
+# pixel CENTRE: x = 0 up to the rounding of the projection (1e-6 px), and whether that pixel's blend weight has a gradient at
+# all (dB/d sdf ~ 100 of a total norm ~500 in G15) is a coin flip of that rounding -- the reference's fp32 and fp64 runs can
+# disagree on it, and so does every other arithmetic.  Pixels with |x| < CENTRE_TOL are taken out.
+CENTRE_TOL = 1e-3
+
+
+def side_ray_cosines(nets, res, cam):
+    """|n . d| at the hit of each side ray of every edge pixel (NaN where the side ray misses): [n_edge, 2]."""
+    from models.raytracer import raytrace_pixels
+    sdf_net = nets["sdf_network"]
+    pts = res["edge_points"].detach()
+    uv = res["edge_uv"].detach()
+    g = sdf_net.gradient(pts).detach().reshape(-1, 3)
+    n3 = g / (g.norm(dim=-1, keepdim=True) + 1e-10)
+    n2 = torch.matmul(n3, cam.W2C[:3, :3].transpose(1, 0))[:, :2]
+    n2 = n2 / (n2.norm(dim=-1, keepdim=True) + 1e-10)
+    centre = torch.floor(uv) + 0.5
+    out = []
+    for side_uv in (centre - 0.707 * n2, centre + 0.707 * n2):
+        with torch.no_grad():
+            r = raytrace_pixels(sdf_net, RayTracer(), side_uv, cam)
+        hit = r["convergent_mask"]
+        cosv = torch.full((uv.shape[0],), float("nan"), dtype=uv.dtype)
+        if hit.any():
+            gn = sdf_net.gradient(r["points"][hit]).detach().reshape(-1, 3)
+            gn = gn / (gn.norm(dim=-1, keepdim=True) + 1e-10)
+            cosv[hit] = (gn * r["ray_d"][hit]).sum(-1).abs()
+        out.append(cosv)
+    return torch.stack(out, dim=-1)
+
+
+def stable_g15():
+    g15 = dict(np.load(os.path.join(HERE, "g15_train_edges_S1.npz")))
+    wt = torch.from_numpy(g15["loss_weights"])
+    dem = torch.from_numpy(g15["depth_edge_mask_input"])
+    # 1. which edge pixels are ill-conditioned: from the fp64 run (the better-defined one)
+    nets64, res64, _, cam64 = edge_training_render(96, torch.float64, depth_edge_mask=dem)
+    cos = side_ray_cosines(nets64, res64, cam64)
+    grazing = (cos < GRAZING).any(dim=-1)
+    # position of the edge point across its pixel disc, as render_edge_pixels computes it
+    pts64, uv64 = res64["edge_points"].detach(), res64["edge_uv"].detach()
+    g = nets64["sdf_network"].gradient(pts64).detach().reshape(-1, 3)
+    n3 = g / (g.norm(dim=-1, keepdim=True) + 1e-10)
+    n2 = torch.matmul(n3, cam64.W2C[:3, :3].transpose(1, 0))[:, :2]
+    n2 = n2 / (n2.norm(dim=-1, keepdim=True) + 1e-10)
+    x = (((uv64 - (torch.floor(uv64) + 0.5)) * n2).sum(-1) / 0.707)
+    rim = (x > RIM) | (x.abs() < CENTRE_TOL)
+    nets32, res32, _, _ = edge_training_render(96, torch.float32, depth_edge_mask=dem)
+    assert torch.equal(res32["edge_pixel_idx"], res64["edge_pixel_idx"])
+    walk_gap = (res32["edge_points"].detach().double() - pts64).norm(dim=-1)
+    chaotic = walk_gap > WALK_TOL
+    bad = grazing | rim | chaotic
+    keep = torch.ones(96 * 96, dtype=torch.bool)
+    keep[res64["edge_pixel_idx"][bad]] = False
+    keep = keep.reshape(96, 96)
+    # 1b. knife-edge pixels of ANY kind (tracer stop |sdf| <= 5e-5, sampler sign, bisection count, walk stop |n.v| <= 0.05):
+    # the forward render is repeated with every SDF weight_v entry nudged by a relative N(0, 2^-23) -- one rounding error's worth --
+    # and a pixel whose colour moves by more than 2e-5 of the image maximum in any of the realisations is not defined by the
+    # algorithm to better than that (on the GPU box's EPYC host the bit-identical torch oracle moves such pixels by 5e-4
+    # against this container's Xeon: tests/diag_g15_host.py).
+    base = res32["color"].detach()
+    spread = torch.zeros(96, 96)
+    edge_flips = 0
+    for k in range(6):
+        netsk = MG.build_reference_networks("S1")
+        gen = torch.Generator().manual_seed(100 + k)
+        with torch.no_grad():
+            for name, p in netsk["sdf_network"].named_parameters():
+                if name.endswith("weight_v"):
+                    p.mul_(1.0 + torch.randn(p.shape, generator=gen) * 2.0 ** -23)
+        with torch.no_grad():
+            pass
+        _, resk, _, _ = edge_training_render(96, torch.float32, depth_edge_mask=dem, nets=netsk)
+        edge_flips += int((resk["edge_mask"] != res32["edge_mask"]).sum())
+        spread = torch.maximum(spread, (resk["color"].detach() - base).abs().max(dim=-1)[0])
+        print("   realisation %d: colour max|d| %.2e, pixels over tolerance so far %d" % (k, float(spread.max()), int((spread > 2e-5 * float(base.max())).sum())), flush=True)
+    knife = spread > 2e-5 * float(base.max())
+    print("G15s: %d knife-edge pixels (%d of them edge pixels), edge-mask flips over the realisations %d" % (
+        int(knife.sum()), int((knife & res32["edge_mask"]).sum()), edge_flips), flush=True)
+    keep &= ~knife
+    print("G15s: of %d edge pixels %d have a side ray with |n.d| < %.2f, %d sit at x > %.2f of the pixel disc or at |x| < 1e-3 (the clamp's corner), %d have fp32/fp64 walks more "
+          "than %.0e apart (median gap %.1e, max %.1e): %d masked" % (cos.shape[0], int(grazing.sum()), GRAZING, int(rim.sum()), RIM,
+                                                                      int(chaotic.sum()), WALK_TOL, float(walk_gap.median()), float(walk_gap.max()), int(bad.sum())), flush=True)
+    wts = wt * keep[..., None].float()
+    # 2. gradients of the masked loss, fp64 and fp32
+    loss64 = (res64["color"] * wts.double()).sum() + 0.1 * (res64["normal"] * wts.double()).sum()
+    loss64.backward()
+    g64 = grads_of(nets64)
+    loss32 = (res32["color"] * wts).sum() + 0.1 * (res32["normal"] * wts).sum()
+    loss32.backward()
+    g32 = grads_of(nets32)
+    out = {"stable_pixel_mask": npf(keep), "grazing_threshold": np.float64(GRAZING), "n_masked_edge_pixels": np.int64(int(bad.sum())),
+           "loss": np.float64(loss32.item()), "loss_fp64": np.float64(loss64.item()), "side_ray_cosines_fp64": npf(cos),
+           "disc_position_fp64": npf(x), "walk_gap_32_64": npf(walk_gap), "edge_pixel_idx": npf(res64["edge_pixel_idx"]),
+           "edge_points_fp64": npf(pts64), "colour_spread_over_realisations": npf(spread)}
+    worst_n = worst_s = 0.0
+    for key in g64:
+        idx = sample_idx(g64[key].size)
+        n32, n64 = np.linalg.norm(g32[key]), np.linalg.norm(g64[key])
+        out["gnorm:" + key], out["gsample:" + key] = np.float64(n32), g32[key][idx]
+        out["gnorm64:" + key], out["gsample64:" + key] = np.float64(n64), g64[key][idx]
+        en = abs(n32 - n64) / max(n64, 1e-12)
+        es = float(np.abs(g32[key][idx] - g64[key][idx]).max() / max(np.abs(g64[key][idx]).max(), 1e-12))
+        out["floor_n:" + key], out["floor_s:" + key] = np.float64(en), np.float64(es)
+        worst_n, worst_s = max(worst_n, en), max(worst_s, es)
+    np.savez_compressed(os.path.join(HERE, "g15s_train_edges_stable_S1.npz"), **out)
+    meta_path = os.path.join(HERE, "meta.json")
+    meta = json.load(open(meta_path))
+    meta["g15s_ref32_vs_ref64_worst_gnorm_err"] = worst_n
+    meta["g15s_ref32_vs_ref64_worst_gsample_err"] = worst_s
+    meta["g15s_masked_edge_pixels"] = int(bad.sum())
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print("G15s floor: ref32 vs ref64 worst gnorm err %.3e, worst sampled entry %.3e" % (worst_n, worst_s))
+
+
+if __name__ == "__main__" and "--stable" in sys.argv:
+    stable_g15()

@@ -151,3 +151,59 @@ def test_nerf_background_field():
     ra, rc = rel_l2(alpha.cpu().numpy(), g["nerf_alpha"]), rel_l2(rgb.cpu().numpy(), g["nerf_rgb"])
     print("NeRF: alpha rel-L2 %.2e  rgb rel-L2 %.2e" % (ra, rc))
     assert ra <= 1e-5 and rc <= 1e-5
+
+
+def test_material_predictor_and_bulk_query():
+    """render_surface.py:434-450 + the query loop of export_materials.py:181-191: values vs the oracle on surface points, and
+    the bulk form is invariant to how the points are split."""
+    from iron_amd.rendering_func import MaterialPredictor, query_materials
+    from oracle import iron_ref as R
+    from _util import oracle_scene
+    cpu = scenes.build_networks("S1")
+    sc = oracle_scene(cpu)
+    nets = {k: v.cuda() for k, v in cpu.items()}
+    gen = torch.Generator().manual_seed(5)
+    pts = torch.nn.functional.normalize(torch.randn(3001, 3, generator=gen), dim=-1) * 0.5
+    mp = MaterialPredictor(nets["sdf_network"], nets)
+    kd, ks, rough = mp(pts.cuda())
+    _, feat, grad = R.sdf_get_all(sc.sdf_sd, sc.sdf_spec, pts)
+    nrm = grad / (grad.norm(dim=-1, keepdim=True) + 1e-10)
+    ref = R.get_materials(sc.nets, pts, nrm, feat)
+    for got, key in ((kd, "diffuse_albedo"), (ks, "specular_albedo"), (rough, "specular_roughness")):
+        want = ref[key].numpy()
+        err = np.abs(got.cpu().numpy().reshape(want.shape) - want).max()
+        assert err <= 2e-5, (key, err)
+    big = pts.cuda().repeat(120, 1)[:350001]
+    a = query_materials(mp, big, max_num_pts=320000)
+    b = query_materials(mp, big, max_num_pts=100003)
+    assert a.shape == (350001, 7) and torch.equal(a, b)
+    assert torch.equal(a[:3001, 0:3], kd) and torch.equal(a[:3001, 6:7], rough.reshape(-1, 1))
+    assert float(a[:, 6].min()) >= 0.01 and torch.isfinite(a).all()
+
+
+def test_smith_g1_and_sample_pdf_operators():
+    """The two small operators of the surface that the fused kernels otherwise absorb: smithG1 (renderer_ggx.py:12-16) and
+    sample_pdf (renderer.py:45-75), against their torch expressions / the oracle."""
+    from iron_amd.renderer import sample_pdf
+    from iron_amd.renderer_ggx import smithG1
+    from oracle import neus_ref as N
+    gen = torch.Generator().manual_seed(9)
+    c = torch.rand(500, 1, generator=gen).clamp(1e-5, 0.99999)
+    al = torch.rand(500, 1, generator=gen) * 2 + 1e-4
+    got = smithG1(c.cuda(), al.cuda()).cpu()
+    root = al * (torch.sqrt(1.0 - c * c) / (c + 1e-10))
+    want = 2.0 / (1.0 + torch.hypot(root, torch.ones_like(root)))
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
+    assert smithG1(c.cuda(), torch.tensor([[0.3]]).cuda()).shape == (500, 1)      # broadcasting like the tensor expression
+    bins = torch.sort(torch.rand(37, 24, generator=gen) * 3, dim=-1)[0]
+    w = torch.rand(37, 23, generator=gen) ** 3
+    w[5] = 0.0                                                                      # a flat row: the 1e-5 floor decides
+    got = sample_pdf(bins.cuda(), w.cuda(), 16, det=True).cpu()
+    want = N.sample_pdf(bins, w, 16, det=True)
+    err = (got - want).abs()
+    # a position that falls into a section of tiny probability is (u - cdf_below) / denom with denom ~1e-4: the 6e-8 by which
+    # two summation orders of the CDF differ becomes ~1e-4 of that section's width; everywhere else the agreement is at rounding
+    assert float(err.max()) <= 2e-4 and float(err.flatten().kthvalue(int(0.97 * err.numel()))[0]) <= 2e-6, (float(err.max()), int(err.argmax()))
+    torch.manual_seed(3)
+    r = sample_pdf(bins.cuda(), w.cuda(), 64, det=False).cpu()                     # random draws: inside the bins, right shape
+    assert r.shape == (37, 64) and bool((r >= bins[:, :1] - 1e-6).all()) and bool((r <= bins[:, -1:] + 1e-6).all())

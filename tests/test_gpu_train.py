@@ -242,19 +242,48 @@ def _check_against_golden(nets, g, tol_n=5e-4, tol_s=2e-3):
     return n, worst_n, worst_s
 
 
-def test_g15_training_render_with_edge_sampling():
-    """render_camera(handle_edges=True, is_training=True): the setting render_surface.py trains with.  96x96 view of S1, 122
-    edge pixels (blend weights + both side colours in the graph), behind the fixture's depth-edge mask; vs the REAL
-    reference (golden G15)."""
+def _grads_vs_fp64_reference(nets, g, g64_prefix_n, g64_prefix_s, floor_of, base_n=2e-3, base_s=4e-3, only=None):
+    """Every parameter tensor's gradient against the reference's fp64 run, tolerance = max(base, 1.5 x the reference's own
+    fp32-vs-fp64 discrepancy for THAT tensor) -- the conditioning floor recorded next to the golden (make_golden_train.py)."""
+    worst = {"n": 0.0, "s": 0.0, "fn": 0.0, "fs": 0.0}
+    bad, n = [], 0
+    for name in NETS:
+        if only is not None and name not in only:
+            continue
+        for pname, p in nets[name].named_parameters():
+            key = "%s/%s" % (name, pname)
+            gr = p.grad.reshape(-1).double().cpu().numpy()
+            idx = np.concatenate([np.arange(min(16, gr.size)), np.linspace(0, gr.size - 1, 32).astype(np.int64)])
+            ref_n, ref_s = float(g[g64_prefix_n + key]), g[g64_prefix_s + key]
+            fn, fs = floor_of(key)
+            en = abs(np.linalg.norm(gr) - ref_n) / max(ref_n, 1e-12)
+            es = float(np.abs(gr[idx] - ref_s).max() / max(np.abs(ref_s).max(), 1e-12))
+            for k, v in (("n", en), ("s", es), ("fn", fn), ("fs", fs)):
+                worst[k] = max(worst[k], v)
+            if en > max(base_n, 1.5 * fn) or es > max(base_s, 1.5 * fs):
+                bad.append((key, "norm %.2e (floor %.2e)" % (en, fn), "entries %.2e (floor %.2e)" % (es, fs)))
+            n += 1
+    return n, worst, bad
+
+
+def _render_edges_training(g, dem, scene="S1"):
     from iron_amd import scenes
     from iron_amd.raytracer import Camera, RayTracer, render_camera
     from iron_amd.renderer_ggx import GGXColocatedRenderer
     from iron_amd.rendering_func import make_render_fn
-    g = golden("g15_train_edges_S1.npz")
-    nets = {k: v.cuda() for k, v in scenes.build_networks("S1").items()}
+    nets = {k: v.cuda() for k, v in scenes.build_networks(scene).items()}
     cam = Camera(int(g["W"]), int(g["H"]), t(g["K"]).cuda(), t(g["W2C"]).cuda())
     res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, make_render_fn(GGXColocatedRenderer(use_cuda=True)),
-                        fill_holes=False, handle_edges=True, is_training=True, depth_edge_mask=t(g["depth_edge_mask_input"]).cuda())
+                        fill_holes=False, handle_edges=True, is_training=True, depth_edge_mask=dem.cuda())
+    return nets, res
+
+
+def test_g15_training_render_with_edge_sampling():
+    """render_camera(handle_edges=True, is_training=True): the setting render_surface.py trains with.  96x96 view of S1, 122
+    edge pixels (blend weights + both side colours in the graph), behind the fixture's depth-edge mask; vs the REAL
+    reference (golden G15 = its fp32 run, g15_floor_fp64 = its fp64 run and the fp32-vs-fp64 discrepancy per tensor)."""
+    g, f = golden("g15_train_edges_S1.npz"), golden("g15_floor_fp64.npz")
+    nets, res = _render_edges_training(g, t(g["depth_edge_mask_input"]))
     assert np.array_equal(res["edge_mask"].cpu().numpy(), g["edge_mask"])
     assert np.array_equal(res["convergent_mask"].cpu().numpy(), g["convergent_mask"])
     col = res["color"].detach().cpu().numpy()
@@ -264,12 +293,74 @@ def test_g15_training_render_with_edge_sampling():
     loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
     assert abs(loss.item() - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
     loss.backward()
-    # The edge term is ill-conditioned by construction: the silhouette walk (16 steps along n - v/(n.v), |n.v| down to 0.05)
-    # turns 1e-6 of rounding into ~1e-5 of edge-point position (the inference tests see the same, test_gpu_edges), and the
-    # blend weight 1 - (a - sin a)/2pi, a = 2 acos(x/0.707), has an unbounded derivative in x.  With the same edge points the
-    # SDF gradients agree to 1e-3 (next test); with each side's own walk the full-loss gradients agree to a few per cent.
+    floor = lambda key: (float(f["floor_n:" + key]), float(f["floor_s:" + key]))
+    # The three material networks: tolerance max(2e-3, 1.5 x floor), measured 1e-6 ... 5e-5.
+    n_m, w_m, bad = _grads_vs_fp64_reference(nets, f, "gnorm:", "gsample:", floor, only=NETS[1:])
+    assert not bad, bad
+    # The SDF network of THIS fixture is not defined by the algorithm to better than a few per cent: 5 of the 122 edge points are
+    # candidates that were already "found" before walking, so they project onto their pixel CENTRE and x = h / 0.707 = 0 up to
+    # the rounding of the projection; torch.clamp(x, 0, 1) passes gradient for x >= +0 and none below, so whether such a pixel's
+    # blend weight has a gradient at all -- each ~100 of a total |dB/d sdf| ~ 500 -- is decided by 1e-6 px of rounding (found
+    # with tests/diag_g15_dump.py: one of them, pixel 4821, has the gradient in this path and on the GPU box's EPYC host CPU,
+    # not in the build container's Xeon run that made the fixture).  The bound here is therefore loose; the same render with
+    # those pixels and the other rounding-decided ones out of the loss is held to the floor in the next test, and the C3 size
+    # itself (G17, 2359 edge pixels) in the one after.
     n, wn, ws = _check_against_golden(nets, g, tol_n=3e-2, tol_s=6e-2)
-    print("G15: %d parameter tensors, worst |norm| error %.2e, worst sampled-entry error %.2e (of max)" % (n, wn, ws))
+    print("G15: material nets vs ref64 worst |norm| %.2e entries %.2e (floors %.2e / %.2e); all %d tensors vs ref32 worst |norm| %.2e "
+          "entries %.2e" % (w_m["n"], w_m["s"], w_m["fn"], w_m["fs"], n, wn, ws))
+    assert n == golden_meta()["n_param_tensors_train_golden"]
+
+
+def test_g15s_edge_sampling_gradients_on_the_well_defined_pixels():
+    """G15 with the pixels whose contribution is decided by rounding taken out of the loss -- found on the REFERENCE side by
+    make_golden_train.py --stable: edge points projecting onto the clamp corner x = 0 (or near the rim x -> 1), side rays
+    grazing at |n.d| < 0.1, walks the reference's own fp32 / fp64 runs place > 1e-5 apart, and every pixel whose colour moves
+    by > 2e-5 when the SDF weights are nudged by one rounding error (6 realisations).  The mask is a fixture INPUT; golden
+    values are the reference's fp32 and fp64 gradients of the masked loss.  Tolerance: max(2e-3 | 4e-3, 1.5 x fp32-vs-fp64 floor)."""
+    g0, g = golden("g15_train_edges_S1.npz"), golden("g15s_train_edges_stable_S1.npz")
+    nets, res = _render_edges_training(g0, t(g0["depth_edge_mask_input"]))
+    wt = (t(g0["loss_weights"]) * t(g["stable_pixel_mask"]).float()[..., None]).cuda()
+    loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
+    assert abs(loss.item() - float(g["loss_fp64"])) <= 2e-4 * abs(float(g["loss_fp64"]))
+    loss.backward()
+    floor = lambda key: (float(g["floor_n:" + key]), float(g["floor_s:" + key]))
+    n, w, bad = _grads_vs_fp64_reference(nets, g, "gnorm64:", "gsample64:", floor)
+    print("G15s (%d edge pixels masked): %d tensors vs ref64 worst |norm| %.2e entries %.2e; the reference's fp32 vs fp64: %.2e / %.2e" % (
+        int(g["n_masked_edge_pixels"]), n, w["n"], w["s"], w["fn"], w["fs"]))
+    assert not bad, bad
+    assert n == golden_meta()["n_param_tensors_train_golden"]
+
+
+def test_g17_c3_training_step_at_512_vs_reference():
+    """BASELINE config C3 at its real size: S1, 512x512, silhouette edge sampling in the graph (87 123 hits, 2 359 edge pixels;
+    the depth-edge mask is the fixture's input as in G8 / G15), loss.backward() through the HIP operators -- against the REAL
+    reference's fp64 run (golden G17, make_golden_train.py --c3: 60 s fp32 + 180 s fp64 on the build container), per tensor
+    within max(2e-3 | 4e-3, 1.5 x the reference's fp32-vs-fp64 discrepancy)."""
+    g = golden("g17_train_c3_S1_512.npz")
+    size = int(g["W"])
+    unpack = lambda key: torch.from_numpy(np.unpackbits(g[key])[: size * size].reshape(size, size).astype(bool))
+    nets, res = _render_edges_training(g, unpack("depth_edge_mask_input_bits"))
+    conv, edge = res["convergent_mask"].cpu(), res["edge_mask"].cpu()
+    flips = int((conv != unpack("convergent_mask_bits")).sum())
+    eflips = int((edge != unpack("edge_mask_bits")).sum())
+    assert flips <= 4 and eflips <= 4, (flips, eflips)
+    col = res["color"].detach().cpu().numpy()[::4, ::4]
+    both = (conv & unpack("convergent_mask_bits")).numpy()[::4, ::4]
+    rel = _rel(col[both], g["color_sub4"][both])
+    yy, xx = np.meshgrid(np.arange(size, dtype=np.float64), np.arange(size, dtype=np.float64), indexing="ij")
+    wt = np.stack([0.2 + 0.5 * np.sin(0.37 * xx + 0.11 * yy + 1.3 * c) + 0.3 * np.cos(0.05 * xx - 0.23 * yy) for c in range(3)], axis=-1)
+    wt = torch.from_numpy(wt.astype(np.float32)).cuda()
+    loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
+    loss.backward()
+    floor = lambda key: (float(g["floor_n:" + key]), float(g["floor_s:" + key]))
+    n, w, bad = _grads_vs_fp64_reference(nets, g, "gnorm64:", "gsample64:", floor)
+    print("G17 (C3, 512x512): hits %d (reference %d), edge pixels %d (%d), mask flips %d / %d, colour rel-L2 %.2e, loss %.4f (ref64 %.4f); "
+          "%d tensors vs ref64 worst |norm| %.2e entries %.2e; the reference's fp32 vs fp64: %.2e / %.2e" % (
+              int(conv.sum()), int(g["n_hits"]), int(edge.sum()), int(g["n_edge"]), flips, eflips, rel, loss.item(), float(g["loss_fp64"]),
+              n, w["n"], w["s"], w["fn"], w["fs"]))
+    assert rel <= 2e-4
+    assert abs(loss.item() - float(g["loss_fp64"])) <= 3e-4 * abs(float(g["loss_fp64"]))
+    assert not bad, bad
     assert n == golden_meta()["n_param_tensors_train_golden"]
 
 
