@@ -79,6 +79,7 @@ class SDFGetAllFn(torch.autograd.Function):
     def forward(ctx, net, x, *params):
         ctx.set_materialize_grads(False)
         ctx.net = net
+        ctx.param_versions = tuple(p._version for p in params)  # backward re-reads the module's parameters: they must not have moved
         with torch.no_grad():
             sdf, feat, grad = net.get_all(x, is_training=False)
         ctx.save_for_backward(x.detach())
@@ -92,6 +93,10 @@ class SDFGetAllFn(torch.autograd.Function):
         x = _lib.require_cuda_f32(x, "x").reshape(-1, 3)
         n = x.shape[0]
         dev = x.device
+        if ctx.param_versions != tuple(p._version for p in _layer_params(net)):
+            raise RuntimeError("a parameter of the SDFNetwork was modified in place between get_all(is_training=True) and backward(); "
+                               "the closed-form backward re-evaluates the forward from the CURRENT parameters (as autograd's own version "
+                               "check would, this refuses instead of returning a gradient of a different function)")
         if net.scale != 1 or len(net.skip_in) > 1:
             raise _lib.IronError("SDF backward supports scale = 1 and at most one skip layer")
         lib = _lib.load_train()

@@ -225,25 +225,47 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sphere(IRON_TRACE_KERNEL_AR
     }
 }
 
+// Samples of one ray evaluated per pass.  A wave's 32 points per pass are 32 / kSamplerBlock rays ("slots"), each marching
+// through its n_steps samples kSamplerBlock at a time and leaving at the first block that holds a negative sample; a finished
+// slot is refilled from the list at once.  The reference evaluates all n_steps samples of every listed ray
+// (raytracer.py:153-166); the finer the block, the fewer evaluations behind the first sign change are executed (block 32:
+// 77 of 128 on average at 800x800 S0; block 8: 65) -- the samples that ARE evaluated, and what is made of them, are the same.
+#ifndef IRON_SAMPLER_BLOCK
+#define IRON_SAMPLER_BLOCK 8
+#endif
+constexpr int kSamplerBlock = IRON_SAMPLER_BLOCK;
+constexpr int kSamplerSlots = 32 / kSamplerBlock;
+static_assert(kSamplerBlock == 4 || kSamplerBlock == 8 || kSamplerBlock == 16 || kSamplerBlock == 32, "sampler block");
+
 template <class BE>
 __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_ARGS) {
     BE be;
     be.init(net, hs, hm);
     const int lane = be.lane;
     const int j = lane & 31;
+    const int slot = j / kSamplerBlock, s_in = j % kSamplerBlock;   // this lane's ray slot and its sample within the slot's block
+    const int slot_lane0 = slot * kSamplerBlock;
+    const unsigned slot_bits = (kSamplerBlock == 32 ? 0xffffffffu : ((1u << kSamplerBlock) - 1u)) << slot_lane0;
     const int n_list = w.cnt->n_sampler;
     long long evals = 0;
-    bool has_ray = false, exhausted = false;
+    bool has_ray = false, exhausted = false;   // has_ray: uniform over the lanes of a slot
     int ray = 0, blk = 0;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, smin = 0.f, width = 0.f, prev_z = 0.f, prev_f = 0.f;
     for (;;) {
-        if (!has_ray && !exhausted) {
-            int i = 0;
-            if (lane == 0) i = atomicAdd(&w.cnt->sampler_head, 1);
-            i = __shfl(i, 0, 64);
-            if (i >= n_list) {
-                exhausted = true;
-            } else {
+        // ---- refill the free slots: one atomicAdd per wave for all of them
+        const unsigned busy = (unsigned)__ballot(has_ray);   // lower 32 bits: lanes 0..31
+        unsigned free_slots = 0;
+#pragma unroll
+        for (int q = 0; q < kSamplerSlots; ++q) free_slots |= ((busy >> (q * kSamplerBlock)) & 1u) ? 0u : (1u << q);
+        if (free_slots && !exhausted) {
+            const int nfree = __popc(free_slots);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&w.cnt->sampler_head, nfree);
+            base = __shfl(base, 0, 64);
+            if (base + nfree >= n_list) exhausted = true;
+            const int rank = __popc(free_slots & ((1u << slot) - 1u));
+            const int i = base + rank;
+            if (!has_ray && i < n_list) {
                 ray = w.sampler_list[i];
                 ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
                 dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
@@ -257,53 +279,44 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
                 has_ray = true;
             }
         }
-        if (!be.any(has_ray)) break;
-        const int idx = blk * 32 + j;
+        if (!be.any(__ballot(has_ray) != 0ull)) break;
+        const int idx = blk * kSamplerBlock + s_in;
         const bool in_range = has_ray && idx < a.n_steps;
         const float z = smin + a.lin[in_range ? idx : a.n_steps - 1] * width;                      // raytracer.py:147-149
         const float qx = has_ray ? ox + dx * z : 0.f, qy = has_ray ? oy + dy * z : 0.f, qz = has_ray ? oz + dz * z : 0.f;  // :150
         const float f = be.eval(qx, qy, qz);
-        if (has_ray) {
-            const int n_in = a.n_steps - blk * 32;
-            evals += n_in < 32 ? n_in : 32;
-            bool done = false, root = false;
-            float z_lo = 0.f, f_lo = 0.f, z_hi = 0.f, f_hi = 0.f;
-            const unsigned neg = (unsigned)__ballot(in_range && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
-            if (neg) {
-                const int first = __ffs(neg) - 1;
-                const int gidx = blk * 32 + first;
-                done = true;
-                if (gidx >= 1) {  // raytracer.py:167
-                    root = true;
-                    z_hi = __shfl(z, first, 64);
-                    f_hi = __shfl(f, first, 64);
-                    const float zl = __shfl(z, first > 0 ? first - 1 : 0, 64);
-                    const float fl = __shfl(f, first > 0 ? first - 1 : 0, 64);
-                    z_lo = first > 0 ? zl : prev_z;
-                    f_lo = first > 0 ? fl : prev_f;
-                }
-            }
-            prev_z = __shfl(z, 31, 64);
-            prev_f = __shfl(f, 31, 64);
-            ++blk;
-            if (blk * 32 >= a.n_steps) done = true;
-            if (done) {
-                if (lane == 0) {
-                    if (root) {
-                        const int pos_l = atomicAdd(&w.cnt->n_root, 1);
-                        w.root_list[pos_l] = ray;
-                        w.root_lo[pos_l] = z_lo; w.root_hi[pos_l] = z_hi;
-                        w.root_flo[pos_l] = f_lo; w.root_fhi[pos_l] = f_hi;
-                    } else {  // raytracer.py:158-160, 75-78: sampled rays without a root get zeros
-                        a.conv[ray] = 0;
-                        a.points[3 * (size_t)ray] = 0.f; a.points[3 * (size_t)ray + 1] = 0.f; a.points[3 * (size_t)ray + 2] = 0.f;
-                        a.sdf[ray] = 0.f;
-                        a.dist[ray] = 0.f;
-                    }
-                }
-                has_ray = false;
+        evals += __popc((unsigned)__ballot(in_range));   // lanes 32..63 mirror 0..31: the low word counts every point once
+        const unsigned neg_all = (unsigned)__ballot(in_range && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
+        // the slot's neighbours' values, fetched by every lane (shuffles are wave-wide operations)
+        const unsigned neg = neg_all & slot_bits;
+        const int first = neg ? (__ffs(neg) - 1) : slot_lane0;          // wave lane of the slot's first negative sample
+        const float z_first = __shfl(z, first, 64), f_first = __shfl(f, first, 64);
+        const float z_before = __shfl(z, first > slot_lane0 ? first - 1 : slot_lane0, 64);
+        const float f_before = __shfl(f, first > slot_lane0 ? first - 1 : slot_lane0, 64);
+        const float z_last = __shfl(z, slot_lane0 + kSamplerBlock - 1, 64), f_last = __shfl(f, slot_lane0 + kSamplerBlock - 1, 64);
+        // outcome of this block for the slot (straight-line: every lane of the slot computes the same)
+        const int gidx = blk * kSamplerBlock + (first - slot_lane0);          // index of the first negative sample, if any
+        const bool found_neg = has_ray && neg != 0u;
+        const bool root = found_neg && gidx >= 1;                              // raytracer.py:167
+        const bool done = has_ray && (found_neg || (blk + 1) * kSamplerBlock >= a.n_steps);
+        const float z_lo = first > slot_lane0 ? z_before : prev_z, f_lo = first > slot_lane0 ? f_before : prev_f;
+        if (done && lane == slot_lane0) {   // the slot's first lane (lower half of the wave) writes the outcome
+            if (root) {
+                const int pos_l = atomicAdd(&w.cnt->n_root, 1);
+                w.root_list[pos_l] = ray;
+                w.root_lo[pos_l] = z_lo; w.root_hi[pos_l] = z_first;
+                w.root_flo[pos_l] = f_lo; w.root_fhi[pos_l] = f_first;
+            } else {  // raytracer.py:158-160, 75-78: sampled rays without a root get zeros
+                a.conv[ray] = 0;
+                a.points[3 * (size_t)ray] = 0.f; a.points[3 * (size_t)ray + 1] = 0.f; a.points[3 * (size_t)ray + 2] = 0.f;
+                a.sdf[ray] = 0.f;
+                a.dist[ray] = 0.f;
             }
         }
+        prev_z = z_last;
+        prev_f = f_last;
+        ++blk;
+        if (done) has_ray = false;
     }
     be.finish();
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
@@ -597,7 +610,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         }
         {
             ProfScope ps(IRON_PROF_SAMPLER, st);
-            launch_trace_kernel(1, h2, sdf, a, w, n, st);
+            launch_trace_kernel(1, h2, sdf, a, w, (n + kSamplerSlots - 1) / kSamplerSlots, st);
         }
         {
             ProfScope ps(IRON_PROF_BISECT_A, st);

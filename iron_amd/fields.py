@@ -74,8 +74,18 @@ class _HipNet(nn.Module):
     def _param_key(self):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
+    def invalidate(self) -> None:
+        """Drop the packed device copy: the next kernel call re-packs from the parameters as they are now.  hip_net() notices
+        assignments and in-place ops on the parameters themselves (optimizer steps, load_state_dict, p.add_()): they bump
+        torch's version counter, which is part of the cache key.  Writes THROUGH `p.data` (p.data.copy_(), EMA or clipping code
+        that goes around autograd) bump nothing: call invalidate() (alias: repack()) after those."""
+        self.__dict__.pop("_hip_cache", None)
+
+    repack = invalidate
+
     def hip_net(self) -> _NetHandle:
-        """The packed device copy of the current parameters (rebuilt if they changed)."""
+        """The packed device copy of the current parameters (rebuilt if they changed; see invalidate() for the one case
+        torch gives no sign of)."""
         key = self._param_key()
         cached = self.__dict__.get("_hip_cache")
         if cached is not None and cached[0] == key:
@@ -210,6 +220,12 @@ class SDFNetwork(_HipNet):
         if is_training:
             # attached to the parameters (to second order through the gradient): HIP forward + iron_sdf_backward
             from .autograd import SDFGetAllFn, _layer_params
+            if x.grad_fn is not None and torch.is_grad_enabled():
+                # the reference propagates through x under create_graph (fields.py:127-134); the closed-form backward here returns
+                # parameter gradients only.  A LEAF x with requires_grad=True stays allowed: the reference sets that flag in place.
+                raise NotImplementedError("SDFNetwork.get_all(is_training=True): x is the result of a differentiable computation and "
+                                          "would silently lose its gradient; pass x.detach() (the stage-2 / NeuS callers evaluate at "
+                                          "detached points) or differentiate w.r.t. x with a torch reference of the network")
             sh = list(x.shape[:-1])
             sdf, feat, grad = SDFGetAllFn.apply(self, x.detach().reshape(-1, 3), *_layer_params(self))
             return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])

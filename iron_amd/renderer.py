@@ -118,6 +118,14 @@ class NeuSRenderer:
             c = self._consts[dev] = (lin, rev)
         return c
 
+    def invalidate(self) -> None:
+        """Forget the cached 1/s (and the networks' packed copies): for parameter writes through `.data`, which torch's version
+        counter does not see (iron_amd.fields._HipNet.invalidate)."""
+        self._inv_s = None
+        for net in (self.sdf_network, self.color_network, self.nerf):
+            if net is not None and hasattr(net, "invalidate"):
+                net.invalidate()
+
     def _inverse_s(self, dev) -> float:
         """deviation_network(zeros[1,3])[:, :1].clip(1e-6, 1e6) (renderer.py:283) as a host scalar, cached per parameter version."""
         var = getattr(self.deviation_network, "variance", None)

@@ -57,6 +57,14 @@ def main():
     for k in ("color", "normal", "distance"):
         out[k] = r32[k].numpy()[::STRIDE, ::STRIDE].astype(np.float32)
         out[k + "_fp64"] = r64[k].numpy()[::STRIDE, ::STRIDE].astype(np.float64)
+    # every pixel, not only the sub-lattice: colour summed over 8x8 tiles (pixels that hit in both runs), fp32 and fp64 run
+    TILE = 8
+    w = both[..., None].astype(np.float64)
+    tiles = lambda img: (img * w).reshape(RES // TILE, TILE, RES // TILE, TILE, 3).sum(axis=(1, 3))
+    out["tile"] = np.int64(TILE)
+    out["color_tile_sum"] = tiles(c32)
+    out["color_tile_sum_fp64"] = tiles(c64)
+    out["tile_hits"] = both.reshape(RES // TILE, TILE, RES // TILE, TILE).sum(axis=(1, 3)).astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "g12_%s_800.npz" % SCENE), **out)
     meta_path = os.path.join(HERE, "meta.json")
     meta = json.load(open(meta_path))

@@ -207,3 +207,33 @@ def test_smith_g1_and_sample_pdf_operators():
     torch.manual_seed(3)
     r = sample_pdf(bins.cuda(), w.cuda(), 64, det=False).cpu()                     # random draws: inside the bins, right shape
     assert r.shape == (37, 64) and bool((r >= bins[:, :1] - 1e-6).all()) and bool((r <= bins[:, -1:] + 1e-6).all())
+
+
+def test_parameter_writes_and_the_packed_copy():
+    """The kernels run on a packed device copy of the parameters.  In-place ops on a parameter re-pack it automatically (version
+    counter); a write through `.data` does not bump the counter and needs invalidate() -- both behaviours are part of the contract
+    (INTEGRATION.md)."""
+    net = scenes.build_networks("S0")["sdf_network"].cuda()
+    x = torch.rand(256, 3, device="cuda") - 0.5
+    y0 = net.sdf(x).clone()
+    with torch.no_grad():
+        net.lin8.bias.add_(0.25)                       # an ordinary in-place update: seen
+    y1 = net.sdf(x)
+    assert float((y1 - y0 - 0.25).abs().max()) <= 1e-6
+    net.lin8.bias.data[0] += 0.5                       # through .data: no version bump, the packed copy is stale ...
+    assert torch.equal(net.sdf(x), y1)
+    net.invalidate()                                   # ... until it is dropped
+    assert float((net.sdf(x) - y1 - 0.5).abs().max()) <= 1e-6
+
+
+def test_get_all_refuses_a_non_leaf_input_and_moved_parameters():
+    net = scenes.build_networks("S0")["sdf_network"].cuda()
+    leaf = (torch.rand(64, 3, device="cuda") - 0.5).requires_grad_(True)
+    net.get_all(leaf, is_training=True)                # a leaf with requires_grad (the reference sets the flag in place): fine
+    with pytest.raises(NotImplementedError):
+        net.get_all(leaf * 1.0, is_training=True)      # a computed x would silently lose its gradient
+    sdf, _, _ = net.get_all(leaf.detach(), is_training=True)
+    with torch.no_grad():
+        net.lin0.bias.add_(1e-3)                       # parameters moved between forward and backward
+    with pytest.raises(RuntimeError):
+        sdf.sum().backward()

@@ -1,0 +1,68 @@
+"""GPU: scene S3 -- the "trained-like" dynamic range (hidden activations in the tens, weight_g rows spanning 250:1, folded
+weights from 1e-8 to 50; iron_amd/scenes.py) -- against the REAL reference's fp32 and fp64 runs (golden G18,
+tests/golden/make_golden_s3.py).  The split-fp16 MLP core carries fp32 values as two fp16 pieces; the geometric-init scenes
+S0-S2 never leave O(1) activations, so this is the fixture that exercises its range: every stage and the end-to-end render must
+stay within max(floor, 1.5 x the reference's own fp32-vs-fp64 discrepancy) of the fp64 run."""
+import numpy as np
+import pytest
+import torch
+
+from iron_amd import scenes
+from iron_amd.raytracer import Camera, RayTracer, render_camera
+from iron_amd.renderer_ggx import GGXColocatedRenderer
+from iron_amd.rendering_func import get_materials, make_render_fn
+
+from _util import golden, golden_meta, rel_l2, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s3():
+    return {k: v.cuda() for k, v in scenes.build_networks("S3").items()}, golden("g18_S3_trained_like.npz")
+
+
+def test_s3_sdf_value_gradient_and_features(s3):
+    nets, g = s3
+    sdf_net = nets["sdf_network"]
+    x = t(g["x"]).cuda()
+    full = sdf_net(x)
+    y, feat, grad = sdf_net.get_all(x, is_training=False)
+    for name, got, k, floor_abs in (("sdf", full[:, 0], "sdf", 1e-6), ("get_all sdf", y[:, 0], "sdf", 1e-6), ("gradient", grad, "grad", 2e-6),
+                                    ("feature", full[:256, 1:], "feature256", 1e-6)):
+        got = got.cpu().numpy()
+        r64, floor = rel_l2(got, g[k + "_fp64"]), rel_l2(g[k], g[k + "_fp64"])
+        print("S3 %-12s rel-L2 hip~ref64 %.2e   ref32~ref64 %.2e   hip~ref32 %.2e" % (name, r64, floor, rel_l2(got, g[k])))
+        assert r64 <= max(floor_abs, 1.5 * floor), (name, r64, floor)
+
+
+def test_s3_material_networks(s3):
+    nets, g = s3
+    pts, nrm, feat = t(g["m_points"]).cuda(), t(g["m_normals"]).cuda(), t(g["m_features"]).cuda()
+    m = get_materials(nets, pts, nrm, feat)
+    for k in ("diffuse_albedo", "specular_albedo", "specular_roughness"):
+        got = m[k].cpu().numpy()
+        r64, floor = rel_l2(got, g["m_" + k + "_fp64"]), rel_l2(g["m_" + k], g["m_" + k + "_fp64"])
+        print("S3 %-20s rel-L2 hip~ref64 %.2e   ref32~ref64 %.2e" % (k, r64, floor))
+        assert r64 <= max(2e-6, 1.5 * floor), (k, r64, floor)
+
+
+def test_s3_render_end_to_end(s3):
+    nets, g = s3
+    cam = Camera(128, 128, t(g["K"]).cuda(), t(g["W2C"]).cuda())
+    res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, make_render_fn(GGXColocatedRenderer(use_cuda=True)),
+                        fill_holes=False, handle_edges=False)
+    conv = res["convergent_mask"].cpu().numpy()
+    m32, m64 = g["r_convergent_mask"], g["r_convergent_mask_fp64"]
+    flips32, flips64, flips_ref = int((conv != m32).sum()), int((conv != m64).sum()), int((m32 != m64).sum())
+    both = conv & m32 & m64
+    col = res["color"].cpu().numpy()
+    r32, r64 = rel_l2(col[both], g["r_color"][both]), rel_l2(col[both], g["r_color_fp64"][both])
+    floor = rel_l2(g["r_color"][both], g["r_color_fp64"][both])
+    dist = np.abs(res["distance"].cpu().numpy()[both] - g["r_distance_fp64"][both])
+    print("S3 128x128: hits %d; mask flips vs ref32 %d, vs ref64 %d (ref32 vs ref64: %d); colour rel-L2 hip~ref32 %.2e hip~ref64 %.2e "
+          "ref32~ref64 %.2e; |d distance| p99 %.1e" % (int(conv.sum()), flips32, flips64, flips_ref, r32, r64, floor, np.percentile(dist, 99)))
+    assert int(conv.sum()) > 3000
+    assert flips64 <= max(4, 2 * flips_ref)
+    assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
+    assert np.percentile(dist, 99) <= 2e-4

@@ -26,7 +26,7 @@ def test_constructors_reproduce_reference_state():
     """The build's SDFNetwork / RenderingNetwork constructors consume the RNG like the reference's
     (models/fields.py:47-76): seeded state dicts hash to the value recorded from the reference."""
     meta = golden_meta()
-    for scene in ("S0", "S1"):
+    for scene in ("S0", "S1", "S3"):
         assert state_hash(scenes.build_networks(scene)) == meta["state_sha256_" + scene]
 
 
