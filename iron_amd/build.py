@@ -15,13 +15,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libiron_hip.so")
-LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/iron_train.h); links rocBLAS
+LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/iron_train.h); hand-written GEMM, no BLAS library
 OBJ_DIR = os.path.join(CSRC, "build")
 MANIFEST = os.path.join(OBJ_DIR, "manifest.json")  # which flag set every translation unit was compiled with (bench.py echoes it)
 
 SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "neus.hip", "profile.hip"]
 TRAIN_SOURCES = ["train.hip"]
-HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
+HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "gemm_h2.h", "iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
 
 BASE_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -105,15 +105,13 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    # the training library: one source, no MFMA cores (its GEMMs are rocBLAS SGEMMs)
-    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
-    cmd = ([hipcc] + BASE_FLAGS + extra_flags + ["-shared", "-o", LIB_TRAIN] + [os.path.join(CSRC, s) for s in TRAIN_SOURCES]
-           + ["-L" + rocm_lib, "-L/opt/rocm/lib", "-lrocblas"])
+    # the training library: one source; its layer products are the split-fp16 MFMA GEMM of gemm_h2.h (no BLAS library linked)
+    cmd = [hipcc] + BASE_FLAGS + extra_flags + ["-shared", "-o", LIB_TRAIN] + [os.path.join(CSRC, s) for s in TRAIN_SOURCES]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for the training library:\n%s\n%s" % (r.stdout, r.stderr))
     for src in TRAIN_SOURCES:
-        used_flags[src] = {"flags": BASE_FLAGS + extra_flags + ["-lrocblas"], "attempt": 0, "fallback": False}
+        used_flags[src] = {"flags": BASE_FLAGS + extra_flags, "attempt": 0, "fallback": False}
     ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
     with open(MANIFEST, "w") as f:
         json.dump({"hipcc": ver[0] if ver else "?", "digest": dig, "units": used_flags,

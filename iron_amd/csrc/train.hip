@@ -1,14 +1,14 @@
 // Backward passes of the stage-2 render operators: see include/iron_train.h.
-// Layer-wise batched formulation: activations recomputed in fp32 and kept in the caller's workspace, per-layer products on
-// rocBLAS SGEMM (plain GEMMs with K = number of points), all glue hand-written below.  One translation unit, its own
-// shared library (libiron_train.so) so the inference library does not pull rocBLAS in.
+// Layer-wise batched formulation: activations recomputed in fp32 and kept in the caller's workspace, per-layer products
+// (plain GEMMs with K = number of points) on the hand-written split-fp16 MFMA GEMM of gemm_h2.h -- no BLAS library --, all glue
+// hand-written below.  One translation unit, its own shared library (libiron_train.so).
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <cstdlib>
 #include <mutex>
 
 #include "../../include/iron_train.h"
+#include "gemm_h2.h"
 
 namespace iron_train {
 
@@ -23,58 +23,71 @@ thread_local int g_blas_status = 0;
             return IRON_ERR_HIP;                     \
         }                                            \
     } while (0)
-#define TR_BLAS(expr)                                \
-    do {                                             \
-        rocblas_status _s = (expr);                  \
-        if (_s != rocblas_status_success) {          \
-            g_blas_status = (int)_s;                 \
-            return IRON_ERR_HIP;                     \
-        }                                            \
-    } while (0)
 #define TR_TRY(expr)                \
     do {                            \
         int _r = (expr);            \
         if (_r != IRON_OK) return _r; \
     } while (0)
 
-// One rocBLAS handle per device is shared by every caller of this library; a handle must not be driven from two host threads
-// at once, so the two GEMM-based entry points serialise per process (the work itself is asynchronous on the caller's stream).
-static std::mutex g_blas_use;
+// What every GEMM of one backward call shares: the caller's stream and a 256-byte device scratch (the |dZ|_max of the GEMM in flight).
+struct GemmCtx {
+    hipStream_t st;
+    float* scratch;
+    float* pack;        // room for the weight operand's fragment image (the dW partial buffer: never in use at the same time)
+    size_t pack_floats;
+};
 
-static rocblas_handle blas_for_current_device() {
-    static std::mutex mu;
-    static rocblas_handle handles[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!handles[dev]) {
-        rocblas_handle h = nullptr;
-        if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
-        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
-        handles[dev] = h;
-    }
-    return handles[dev];
-}
-
-// row-major C[m,n] = op(A) op(B) + beta C;  A is [m,k] (or [k,m] when ta), B is [k,n] (or [n,k] when tb)
-static int gemm_rm(rocblas_handle h, bool ta, bool tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float beta,
-                   float* C, int ldc) {
+// row-major C[m,n] = op(A) op(B) + beta C;  A is [m,k] (or [k,m] when ta), B is [k,n] (or [n,k] when tb).
+// Three shapes occur: Z = X W^T (ta = 0, tb = 1: forward recompute, operands as they are), dX = dZ W (ta = 0, tb = 0) and the
+// small-K leftovers of dW = dZ^T X (ta = 1, tb = 0): in the last two A is a gradient and carries a power-of-two scale from its
+// absolute maximum (gemm_h2.h).
+// `amax`: device scalar already holding |A|_max (written by the kernel that produced A: publish_absmax), or null -> one pass over A.
+static int gemm_rm(const GemmCtx& h, bool ta, bool tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float beta,
+                   float* C, int ldc, const float* amax = nullptr) {
     if (m == 0 || n == 0) return IRON_OK;
-    const float one = 1.0f;
-    TR_BLAS(rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none,
-                          n, m, k, &one, B, ldb, A, lda, &beta, C, ldc));
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.beta = beta;
+    g.k_per_split = (k + kGemmTK - 1) / kGemmTK * kGemmTK;
+    g.a_absmax = nullptr;
+    const bool a_is_gradient = !(tb && !ta);
+    if (a_is_gradient && amax) {
+        g.a_absmax = amax;
+    } else if (a_is_gradient && k > 0) {
+        TR_HIP(hipMemsetAsync(h.scratch, 0, sizeof(float), h.st));
+        const int64_t count = (int64_t)(ta ? k : m) * lda;  // the rows in use are contiguous: lda == row length at every call site
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)((count + 1023) / 1024 < 1024 ? (count + 1023) / 1024 : 1024)), dim3(256), 0, h.st, A, count, h.scratch);
+        g.a_absmax = h.scratch;
+    }
+    // a layer applied to a batch of rows (forward recompute, dX): the row kernel reads A once and writes C once
+    const int k_steps = (k + 15) / 16, n_tiles = (n + 31) / 32;
+    if (!ta && k_steps <= kRowsMaxKSteps && n_tiles <= 12 && (size_t)n_tiles * k_steps * 512 <= h.pack_floats && m >= 256) {
+        PackBArgs pb;
+        pb.B = B; pb.ldb = ldb; pb.N = n; pb.K = k; pb.k_strided = tb ? 0 : 1; pb.n_tiles = n_tiles; pb.k_steps = k_steps; pb.out = (char*)h.pack;
+        hipLaunchKernelGGL(k_gemm_pack_b, dim3(n_tiles * k_steps), dim3(64), 0, h.st, pb);
+        RowsArgs r;
+        r.A = A; r.Bp = (const char*)h.pack; r.C = C; r.lda = lda; r.ldc = ldc; r.R = m; r.N = n; r.K = k; r.k_steps = k_steps; r.n_tiles = n_tiles;
+        r.a_absmax = g.a_absmax; r.beta = beta;
+        const hipError_t er = n_tiles <= 4 ? gemm_rows_launch<1>(r, h.st) : (n_tiles <= 8 ? gemm_rows_launch<2>(r, h.st) : gemm_rows_launch<3>(r, h.st));
+        TR_HIP(er);
+        return IRON_OK;
+    }
+    hipError_t e;
+    if (!ta && tb) e = gemm_split_launch<false, false>(g, 1, h.st);
+    else if (!ta && !tb) e = gemm_split_launch<false, true>(g, 1, h.st);
+    else if (ta && !tb) e = gemm_split_launch<true, true>(g, 1, h.st);
+    else return IRON_ERR_UNSUPPORTED;
+    TR_HIP(e);
     return IRON_OK;
 }
 
-// dW[out,in] = beta dW + dZ[R,out]^T X[R,in].  The output is one or two tiles while K = R is 10^5: a plain SGEMM runs it on a
-// handful of CUs, so K is split into kSplitK strided batches (partials in `partial`, [kSplitK, out*in]) that fill the chip and
-// are then summed; the < kSplitK leftover rows go through one small GEMM.
+// dW[out,in] = beta dW + dZ[R,out]^T X[R,in].  The output is one or two tiles while K = R is 10^5, so K is split over
+// blockIdx.z into partial tiles ([splits, out*in] in `partial`) that fill the chip and are then summed in a fixed order.
 constexpr int kSplitK = 128;  // capacity of the partial buffer; the number of splits in use is split_k()
 static int split_k() {
     static const int v = [] {
-        const char* e = getenv("IRON_TRAIN_SPLITK");  // tuning knob (tools/train_step.py): power of two in [2, 128]
-        const int x = e ? atoi(e) : 64;
-        return x >= 2 && x <= kSplitK ? x : 64;
+        const char* e = getenv("IRON_TRAIN_SPLITK");  // tuning knob (tools/train_step.py): in [2, 128]
+        const int x = e ? atoi(e) : 128;
+        return x >= 2 && x <= kSplitK ? x : 128;
     }();
     return v;
 }
@@ -87,17 +100,28 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, int splits,
     }
 }
 
-static int gemm_dw(rocblas_handle h, hipStream_t st, int out, int in, int R, const float* dZ, const float* X, float beta, float* dW, float* partial) {
-    const int S = split_k();
-    if (R < 64 * S) return gemm_rm(h, true, false, out, in, R, dZ, out, X, in, beta, dW, in);
-    const int kb = R / S;
-    const float one = 1.0f, zero = 0.0f;
-    TR_BLAS(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, in, out, kb, &one, X, in, (rocblas_stride)kb * in, dZ,
-                                          out, (rocblas_stride)kb * out, &zero, partial, in, (rocblas_stride)out * in, S));
-    const int count = out * in;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((count + 255) / 256), dim3(256), 0, st, partial, S, count, beta, dW);
-    const int done = kb * S;
-    if (R > done) return gemm_rm(h, true, false, out, in, R - done, dZ + (size_t)done * out, out, X + (size_t)done * in, in, 1.0f, dW, in);
+static int gemm_dw(const GemmCtx& h, hipStream_t st, int out, int in, int R, const float* dZ, const float* X, float beta, float* dW, float* partial,
+                   const float* amax = nullptr) {
+    if (out == 0 || in == 0) return IRON_OK;
+    int S = split_k();
+    int kps = ((R + S - 1) / S + kGemmTK - 1) / kGemmTK * kGemmTK;      // rows per split, a multiple of the K tile
+    if (kps < 8 * kGemmTK) kps = 8 * kGemmTK;                           // no split shorter than 256 rows
+    S = (R + kps - 1) / kps;
+    if (S <= 1) return gemm_rm(h, true, false, out, in, R, dZ, out, X, in, beta, dW, in, amax);
+    GemmArgs g;
+    g.A = dZ; g.B = X; g.C = partial; g.lda = out; g.ldb = in; g.ldc = in; g.M = out; g.N = in; g.K = R; g.beta = 0.0f;
+    g.k_per_split = kps;
+    if (amax) {
+        g.a_absmax = amax;
+    } else {
+        TR_HIP(hipMemsetAsync(h.scratch, 0, sizeof(float), st));
+        const int64_t count = (int64_t)R * out;
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)((count + 1023) / 1024 < 1024 ? (count + 1023) / 1024 : 1024)), dim3(256), 0, st, dZ, count, h.scratch);
+        g.a_absmax = h.scratch;
+    }
+    TR_HIP((gemm_split_launch<true, true>(g, S, st)));
+    const int cnt = out * in;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((cnt + 255) / 256), dim3(256), 0, st, partial, S, cnt, beta, dW);
     return IRON_OK;
 }
 
@@ -236,23 +260,42 @@ static inline dim3 strip_grid(int m, int out) { return dim3((out + 255) / 256, (
     const int r0 = blockIdx.y * kStrip, r1 = min((m), r0 + kStrip); \
     float colsum = 0.0f;
 
+// |dZ|_max as a by-product of the kernels that WRITE a layer's dZ (the split-fp16 GEMMs scale their gradient operand by it,
+// gemm_h2.h): wave maximum, one atomicMax per wave.  Called by EVERY lane of the wave (STRIP_PROLOGUE_LIVE keeps the lanes of a
+// partial last block alive with `live` = false and m = 0).
+__device__ __forceinline__ void publish_absmax(float m, float* out) {
+    if (!out) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+#define STRIP_PROLOGUE_LIVE(m, out)                             \
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;        \
+    const bool live = c < (out);                                \
+    const int r0 = blockIdx.y * kStrip, r1 = live ? min((m), r0 + kStrip) : r0; \
+    float colsum = 0.0f;
+
 __global__ void k_sdf_seed(const float* __restrict__ d_sdf, const float* __restrict__ d_feat, int m, int out, int tangent, float* __restrict__ dZ,
-                           float* __restrict__ db) {
-    STRIP_PROLOGUE(m, out)
+                           float* __restrict__ db, float* __restrict__ amax) {
+    STRIP_PROLOGUE_LIVE(m, out)
+    float mx = (live && tangent && c == 0) ? 1.0f : 0.0f;
     for (int p = r0; p < r1; ++p) {
         const size_t i = (size_t)p * out + c;
         const float g = c == 0 ? (d_sdf ? d_sdf[p] : 0.0f) : (d_feat ? d_feat[(size_t)p * (out - 1) + c - 1] : 0.0f);
         dZ[i] = g;
         colsum += g;
+        mx = fmaxf(mx, fabsf(g));
         if (tangent) dZ[(size_t)m * out + i] = c == 0 ? 1.0f : 0.0f;  // d<v, grad sdf>/d(tangent output 0) = 1
     }
-    atomicAdd(&db[c], colsum);
+    if (live) atomicAdd(&db[c], colsum);
+    publish_absmax(mx, amax);
 }
 
 // reverse of k_sdf_act: dX [R, ld_dx] holds dL/d(next input) for the columns [0,out); writes dZ [R, out]
 __global__ void k_sdf_act_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, int tangent, float sc,
-                               float* __restrict__ dZ, float* __restrict__ db) {
-    STRIP_PROLOGUE(m, out)
+                               float* __restrict__ dZ, float* __restrict__ db, float* __restrict__ amax) {
+    STRIP_PROLOGUE_LIVE(m, out)
+    float mx = 0.0f;
     for (int p = r0; p < r1; ++p) {
         const size_t i = (size_t)p * out + c;
         float a, s1, s2;
@@ -263,11 +306,14 @@ __global__ void k_sdf_act_back(const float* __restrict__ dX, int ld_dx, const fl
             const float adotbar = dX[(size_t)(m + p) * ld_dx + c] * sc;
             zbar += s2 * Z[(size_t)m * out + i] * adotbar;
             dZ[(size_t)m * out + i] = s1 * adotbar;
+            mx = fmaxf(mx, fabsf(s1 * adotbar));
         }
         dZ[i] = zbar;
         colsum += zbar;
+        mx = fmaxf(mx, fabsf(zbar));
     }
-    atomicAdd(&db[c], colsum);
+    if (live) atomicAdd(&db[c], colsum);
+    publish_absmax(mx, amax);
 }
 
 constexpr int kSdfChunk = 65536;
@@ -276,8 +322,8 @@ constexpr int kMaxLayers = 16;
 struct SdfPlan {
     int L, m_max;
     float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *IN[kMaxLayers], *Z[kMaxLayers];
-    float *dZ, *dX, *partial;
-    size_t bytes;
+    float *dZ, *dX, *partial, *scratch;
+    size_t bytes, partial_floats;
 };
 
 static int sdf_plan(const iron_sdf_train_desc* d, int64_t n, void* ws, SdfPlan& P) {
@@ -305,7 +351,9 @@ static int sdf_plan(const iron_sdf_train_desc* d, int64_t n, void* ws, SdfPlan& 
     }
     P.dZ = b.take(R * maxw);
     P.dX = b.take(R * maxw);
-    P.partial = b.take((size_t)kSplitK * maxw * maxw);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw + 64);  // + 64 floats behind it: the GEMMs' scratch (GemmCtx)
+    P.scratch = P.partial + (size_t)kSplitK * maxw * maxw;
+    P.partial_floats = (size_t)kSplitK * maxw * maxw;
     P.bytes = b.off + 256;
     return IRON_OK;
 }
@@ -315,10 +363,7 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
     SdfPlan P;
     TR_TRY(sdf_plan(d, n, ws, P));
     if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
-    std::lock_guard<std::mutex> blas_lock(g_blas_use);
-    rocblas_handle h = blas_for_current_device();
-    if (!h) return IRON_ERR_HIP;
-    TR_BLAS(rocblas_set_stream(h, st));
+    const GemmCtx h{st, P.scratch, P.partial, P.partial_floats};
     const int L = P.L, D0 = 3 + 6 * d->multires;
     const iron_train_layer* ly = d->layers;
     const float rs2 = 0.70710678118654752440f;
@@ -344,16 +389,19 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
         }
         // reverse
         const int out_last = ly[L - 1].out_dim;
+        float* dz_max = h.scratch + 1;  // |dZ|_max of the layer in flight, written by the kernel that writes dZ
+        TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
         hipLaunchKernelGGL(k_sdf_seed, strip_grid(m, out_last), dim3(256), 0, st, d_sdf ? d_sdf + p0 : nullptr,
-                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ, P.db[L - 1]);
+                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ, P.db[L - 1], dz_max);
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_dw(h, st, out, in, R, P.dZ, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
+            TR_TRY(gemm_dw(h, st, out, in, R, P.dZ, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, dz_max));
             if (l == 0) break;
-            TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
+            TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in, dz_max));
             const int outp = ly[l - 1].out_dim;
+            TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
             hipLaunchKernelGGL(k_sdf_act_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, tangent,
-                               l == d->skip_layer ? rs2 : 1.0f, P.dZ, P.db[l - 1]);
+                               l == d->skip_layer ? rs2 : 1.0f, P.dZ, P.db[l - 1], dz_max);
         }
     }
     for (int l = 0; l < L; ++l) {
@@ -428,15 +476,18 @@ __global__ void k_relu_act(float* __restrict__ Z, const float* __restrict__ bias
 }
 
 __global__ void k_relu_back(const float* __restrict__ dX, int ld_dx, const float* __restrict__ Z, int m, int out, float sc, float* __restrict__ dZ,
-                            float* __restrict__ db) {
-    STRIP_PROLOGUE(m, out)
+                            float* __restrict__ db, float* __restrict__ amax) {
+    STRIP_PROLOGUE_LIVE(m, out)
+    float mx = 0.0f;
     for (int p = r0; p < r1; ++p) {
         const size_t i = (size_t)p * out + c;
         const float g = Z[i] > 0.0f ? dX[(size_t)p * ld_dx + c] * sc : 0.0f;
         dZ[i] = g;
         colsum += g;
+        mx = fmaxf(mx, fabsf(g));
     }
-    atomicAdd(&db[c], colsum);
+    if (live) atomicAdd(&db[c], colsum);
+    publish_absmax(mx, amax);
 }
 
 // last layer: z = Z + b; y = os (z + ob); optionally sq * sigmoid(y); dZ = dL/dz
@@ -464,8 +515,8 @@ struct RenderPlan {
     int L, m_max;
     RenderIn in;
     float *W[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *X[kMaxLayers], *Z[kMaxLayers];
-    float *dZ, *dX, *dIN0, *partial;
-    size_t bytes;
+    float *dZ, *dX, *dIN0, *partial, *scratch;
+    size_t bytes, partial_floats;
 };
 
 static int render_plan(const iron_render_train_desc* d, int64_t n, void* ws, RenderPlan& P) {
@@ -493,7 +544,9 @@ static int render_plan(const iron_render_train_desc* d, int64_t n, void* ws, Ren
     P.dZ = b.take(R * maxw);
     P.dX = b.take(R * maxw);
     P.dIN0 = b.take(R * P.in.D0);
-    P.partial = b.take((size_t)kSplitK * maxw * maxw);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw + 64);  // + 64 floats behind it: the GEMMs' scratch (GemmCtx)
+    P.scratch = P.partial + (size_t)kSplitK * maxw * maxw;
+    P.partial_floats = (size_t)kSplitK * maxw * maxw;
     P.bytes = b.off + 256;
     return IRON_OK;
 }
@@ -506,10 +559,7 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
     if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
     const RenderIn& I = P.in;
     if (n > 0 && (!pts || !d_out || (I.nf && !feat) || (I.nn && !nrm) || (I.nv && !view))) return IRON_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> blas_lock(g_blas_use);
-    rocblas_handle h = blas_for_current_device();
-    if (!h) return IRON_ERR_HIP;
-    TR_BLAS(rocblas_set_stream(h, st));
+    const GemmCtx h{st, P.scratch, P.partial, P.partial_floats};
     const int L = P.L;
     const iron_train_layer* ly = d->layers;
     const float rs2 = 0.70710678118654752440f;
@@ -538,10 +588,12 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
         hipLaunchKernelGGL(k_render_out_back, strip_grid(m, out_last), dim3(256), 0, st, P.Z[L - 1], ly[L - 1].bias, d_out + (size_t)p0 * out_last, m,
                            out_last, d->output_bias, d->output_scale, d->squeeze_out, d->squeeze_out_scale, P.dZ, P.db[L - 1]);
         TR_HIP(hipMemsetAsync(P.dIN0, 0, sizeof(float) * (size_t)m * I.D0, st));
+        float* dz_max = h.scratch + 1;  // |dZ|_max of the layer in flight, written by k_relu_back (the 3-wide seed of the last layer: one tiny pass)
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_dw(h, st, out, in, m, P.dZ, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial));
-            TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in));
+            const float* known = l == L - 1 ? nullptr : dz_max;
+            TR_TRY(gemm_dw(h, st, out, in, m, P.dZ, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, known));
+            TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in, known));
             if (l == 0) {
                 hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, 0, m, I.D0, 1.0f, P.dIN0, I.D0);
                 break;
@@ -549,7 +601,8 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
             const int outp = ly[l - 1].out_dim;
             const bool is_skip = (l == d->skip_layer);
             if (is_skip) hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, outp, m, I.D0, rs2, P.dIN0, I.D0);
-            hipLaunchKernelGGL(k_relu_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ, P.db[l - 1]);
+            TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ, P.db[l - 1], dz_max);
         }
         hipLaunchKernelGGL(k_render_in_back, dim3((m + 255) / 256), dim3(256), 0, st, I, cp, cv, m, P.dIN0, d_pts ? d_pts + 3 * p0 : nullptr,
                            (d_view && I.nv) ? d_view + 3 * p0 : nullptr, d_nrm ? d_nrm + 3 * p0 : nullptr);
@@ -909,8 +962,8 @@ constexpr int kNerfChunk = 131072;
 struct NerfPlan {
     int D, W, in_p, in_v, nl, m_max;
     float *Wt[kMaxLayers], *dW[kMaxLayers], *db[kMaxLayers], *X[kMaxLayers], *Z[kMaxLayers];
-    float *HV, *ZV, *AV, *dA, *dB, *partial;
-    size_t bytes;
+    float *HV, *ZV, *AV, *dA, *dB, *partial, *scratch;
+    size_t bytes, partial_floats;
 };
 
 static int nerf_plan(const iron_nerf_train_desc* d, int64_t n, void* ws, NerfPlan& P) {
@@ -946,7 +999,9 @@ static int nerf_plan(const iron_nerf_train_desc* d, int64_t n, void* ws, NerfPla
     P.AV = b.take(R * ly[d->D + 2].out_dim);
     P.dA = b.take(R * maxw);
     P.dB = b.take(R * maxw);
-    P.partial = b.take((size_t)kSplitK * maxw * maxw);
+    P.partial = b.take((size_t)kSplitK * maxw * maxw + 64);  // + 64 floats behind it: the GEMMs' scratch (GemmCtx)
+    P.scratch = P.partial + (size_t)kSplitK * maxw * maxw;
+    P.partial_floats = (size_t)kSplitK * maxw * maxw;
     P.bytes = b.off + 256;
     return IRON_OK;
 }
@@ -956,10 +1011,7 @@ static int nerf_backward(const iron_nerf_train_desc* d, const float* pts, const 
     NerfPlan P;
     TR_TRY(nerf_plan(d, n, ws, P));
     if (P.bytes > ws_bytes) return IRON_ERR_WORKSPACE;
-    std::lock_guard<std::mutex> blas_lock(g_blas_use);
-    rocblas_handle h = blas_for_current_device();
-    if (!h) return IRON_ERR_HIP;
-    TR_BLAS(rocblas_set_stream(h, st));
+    const GemmCtx h{st, P.scratch, P.partial, P.partial_floats};
     const iron_train_layer* ly = d->layers;
     const int D = P.D, W = P.W, iA = D, iF = D + 1, iV = D + 2, iC = D + 3;
     const int wv = ly[iV].out_dim, hD = ly[iA].in_dim;
@@ -1001,7 +1053,7 @@ static int nerf_backward(const iron_nerf_train_desc* d, const float* pts, const 
             TR_TRY(gemm_dw(h, st, 3, wv, m, g, P.AV, beta, P.dW[iC], P.partial));
             hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, 3), dim3(256), 0, st, g, 3, (const float*)nullptr, m, 3, (float*)nullptr, 0, P.db[iC]);
             TR_TRY(gemm_rm(h, false, false, m, wv, 3, g, 3, P.Wt[iC], wv, 0.0f, P.dB, wv));                               // dL/d av
-            hipLaunchKernelGGL(k_relu_back, strip_grid(m, wv), dim3(256), 0, st, P.dB, wv, P.ZV, m, wv, 1.0f, P.AV, P.db[iV]);  // AV <- dL/d zv
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, wv), dim3(256), 0, st, P.dB, wv, P.ZV, m, wv, 1.0f, P.AV, P.db[iV], (float*)nullptr);  // AV <- dL/d zv
             TR_TRY(gemm_dw(h, st, wv, inv, m, P.AV, P.HV, beta, P.dW[iV], P.partial));
             TR_TRY(gemm_rm(h, false, false, m, inv, wv, P.AV, wv, P.Wt[iV], inv, 0.0f, P.dB, inv));                        // dL/d hv; [:, :W] = dL/d feature
             hipLaunchKernelGGL(k_bias_copy_colsum, strip_grid(m, W), dim3(256), 0, st, P.dB, inv, (const float*)nullptr, m, W, P.HV, W, P.db[iF]);                                                                                // HV[:, :W] (ld W) <- dL/d feature
@@ -1018,7 +1070,7 @@ static int nerf_backward(const iron_nerf_train_desc* d, const float* pts, const 
             const int in = ly[i].in_dim;
             const int ld = i + 1 < D ? ly[i + 1].in_dim : hD;
             const int off = (i == d->skip) ? P.in_p : 0;
-            hipLaunchKernelGGL(k_relu_back, strip_grid(m, W), dim3(256), 0, st, P.dA + off, ld, P.Z[i], m, W, 1.0f, P.dB, P.db[i]);  // dB = dL/d z_i
+            hipLaunchKernelGGL(k_relu_back, strip_grid(m, W), dim3(256), 0, st, P.dA + off, ld, P.Z[i], m, W, 1.0f, P.dB, P.db[i], (float*)nullptr);  // dB = dL/d z_i
             TR_TRY(gemm_dw(h, st, W, in, m, P.dB, P.X[i], beta, P.dW[i], P.partial));
             if (i > 0) TR_TRY(gemm_rm(h, false, false, m, in, W, P.dB, W, P.Wt[i], in, 0.0f, P.dA, in));
         }
@@ -1242,7 +1294,7 @@ extern "C" int iron_composite_colocated_backward(float light, const float* dista
 
 
 extern "C" int iron_train_last_hip_error(void) { return g_hip_error; }
-extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }
+extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }  // kept for ABI stability: there is no BLAS any more, always 0
 
 extern "C" size_t iron_sdf_backward_workspace_bytes(const iron_sdf_train_desc* desc, int64_t n) {
     SdfPlan P;

@@ -195,6 +195,22 @@ def test_fullsize_silhouette_handling_invariants(frame800):
     assert torch.equal(d2, depth)
 
 
+def _tile_colour_check(res, g, label):
+    """Every pixel, not only the sub-lattice: colour summed over 8x8 tiles (pixels that hit in the reference's fp32 AND fp64
+    runs) against the reference's fp64 tile sums; the reference's own fp32 tile sums give the floor."""
+    n, T = int(g["res"]), int(g["tile"])
+    m = (np.unpackbits(g["mask_bits"])[: n * n].astype(bool) & np.unpackbits(g["mask64_bits"])[: n * n].astype(bool)).reshape(n, n)
+    col = res["color"].cpu().numpy().astype(np.float64) * m[..., None]
+    mine = col.reshape(n // T, T, n // T, T, 3).sum(axis=(1, 3))
+    ref64, ref32 = g["color_tile_sum_fp64"], g["color_tile_sum"]
+    r64 = float(np.linalg.norm(mine - ref64) / np.linalg.norm(ref64))
+    floor = float(np.linalg.norm(ref32 - ref64) / np.linalg.norm(ref64))
+    worst = np.abs(mine - ref64).max(axis=-1) / np.maximum(g["tile_hits"], 1)
+    print("%s: all %d pixels in 8x8 tiles: colour tile-sum rel-L2 hip~ref64 %.3e (ref32~ref64 %.3e); worst tile mean |d| per hit %.2e" % (
+        label, n * n, r64, floor, worst.max()))
+    return r64, floor, float(worst.max())
+
+
 def test_fullsize_vs_reference_golden(frame800):
     """BASELINE config C1 itself against the REAL reference (tests/golden/make_golden_800.py: fp32 and fp64 runs of the
     reference's render_camera at 800x800): the complete hit mask, and colour / normal / distance on the [::4, ::4]
@@ -219,9 +235,10 @@ def test_fullsize_vs_reference_golden(frame800):
           "  |d distance| p99 %.2e max %.2e" % (flips, flips_ref, r32, r64, floor, np.percentile(dist, 99), dist.max()))
     assert int(conv.sum()) == golden_meta()["n_conv_S0_800"]
     assert flips <= max(2, 2 * flips_ref)
-    assert r32 <= max(1e-4, 1.5 * floor), (r32, floor)
-    assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
+    assert r32 <= 1e-4 and r64 <= 1e-4, (r32, r64)          # the north_star bound itself, against both runs (measured 1e-5)
     assert np.percentile(dist, 99) <= 2e-4
+    t64, tfloor, tworst = _tile_colour_check(res, g, "800x800 S0")
+    assert t64 <= 1e-4 and tworst <= 2e-3, (t64, tworst)
 
 
 def test_fullsize_bumpy_scene_vs_reference_golden():
@@ -249,6 +266,10 @@ def test_fullsize_bumpy_scene_vs_reference_golden():
     print("800x800 S1: mask flips %d (reference fp32 vs fp64: %d)  colour rel-L2 hip~ref32 %.3e  hip~ref64 %.3e  ref32~ref64 %.3e"
           "  |d distance| p99 %.2e max %.2e" % (flips, flips_ref, r32, r64, floor, np.percentile(dist, 99), dist.max()))
     assert flips <= max(4, 2 * flips_ref)
+    # the fixed north_star bound against the reference's fp64 run (measured 6e-5).  Against its fp32 run the figure (1.9e-4) is
+    # information only: on this chaotic scene the reference's own fp32 and fp64 renders are 2.0e-4 apart on these pixels.
+    assert r64 <= 1e-4, (r64, floor)
     assert r32 <= max(1e-4, 1.5 * floor), (r32, floor)
-    assert r64 <= max(1e-4, 1.5 * floor), (r64, floor)
     assert np.percentile(dist, 99) <= 2e-4
+    t64, tfloor, tworst = _tile_colour_check(res, g, "800x800 S1")
+    assert t64 <= max(1e-4, 1.5 * tfloor), (t64, tfloor)
