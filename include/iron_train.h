@@ -164,7 +164,17 @@ typedef struct iron_neus_composite_grads {
 } iron_neus_composite_grads;
 int iron_neus_composite_backward(const iron_neus_composite_args* fwd, const iron_neus_composite_grads* grads, void* stream);
 
-/* Diagnostics: last hipError_t / rocblas_status seen by this library on the calling thread. */
+/* The layer product every backward pass above is built from, on its own (tests / micro-benchmarks): row-major
+ * C[m,n] = op(A) op(B) + beta C in fp32, computed by the library's hand-written split-fp16 MFMA GEMMs (csrc/gemm_h2.h; no BLAS
+ * library).  op = 0: operand as stored ([m,k] / [k,n]); 1: transposed ([k,m] / [n,k]).  (0,1) = Z = X W^T, (0,0) = dX = dZ W,
+ * (1,0) = dW = dZ^T X (there lda = m, ldb = n, ldc = n are implied: tightly packed, as inside the library); (1,1) is refused.
+ * In (0,0) and (1,0) A is treated as a gradient: scaled by a power of two from its absolute maximum before the fp16 split. */
+size_t iron_train_gemm_workspace_bytes(int32_t op_a, int32_t m, int32_t n);
+int iron_train_gemm(int32_t op_a, int32_t op_b, int32_t m, int32_t n, int32_t k, const float* A, int32_t lda, const float* B, int32_t ldb,
+                    float beta, float* C, int32_t ldc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Diagnostics: last hipError_t seen by this library on the calling thread (iron_train_last_blas_status: kept for ABI
+ * stability from the rocBLAS days, always 0). */
 int iron_train_last_hip_error(void);
 int iron_train_last_blas_status(void);
 

@@ -171,6 +171,8 @@ class iron_neus_composite_grads(C.Structure):
 
 TRAIN_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libiron_train.so")
 TRAIN_SYMBOLS = {
+    "iron_train_gemm_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "iron_train_gemm": (C.c_int, [_I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _F, _P, _I32, _P, _SZ, _P]),
     "iron_sdf_backward_workspace_bytes": (_SZ, [C.POINTER(iron_sdf_train_desc), _I64]),
     "iron_sdf_backward": (C.c_int, [C.POINTER(iron_sdf_train_desc), _P, _I64, _P, _P, _P, _P, _SZ, _P]),
     "iron_render_backward_workspace_bytes": (_SZ, [C.POINTER(iron_render_train_desc), _I64]),

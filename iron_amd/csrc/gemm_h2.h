@@ -95,11 +95,26 @@ struct GemmLoader {
                     const float4 t = *reinterpret_cast<const float4*>(base + (size_t)(k0 + i) * ld + r4);
                     v[0][i] = t.x * scale; v[1][i] = t.y * scale; v[2][i] = t.z * scale; v[3][i] = t.w * scale;
                 }
-            } else {
+            } else if (vec_ok) {   // aligned operand, ragged edge of the matrix
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q][i] = (r4 + q < rows && k0 + i < k_end) ? base[(size_t)(k0 + i) * ld + r4 + q] * scale : 0.0f;
+            } else {               // rows not 16-byte aligned (ld = 39, 217, 257, ...): thread w -> row w, segment q = k-chunk q; every
+                                   // dword load of a wave covers 64 consecutive rows of one k (256 contiguous bytes)
+                const int gr = row0 + w;
+                const float* p = base + (size_t)kbase * ld + gr;
+                if (gr < rows && kbase + 32 <= k_end) {     // the common case: no per-element checks, one running pointer
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[q][i] = p[(size_t)(8 * q + i) * ld] * scale;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[q][i] = (gr < rows && kbase + 8 * q + i < k_end) ? p[(size_t)(8 * q + i) * ld] * scale : 0.0f;
+                }
             }
         } else {
             const int gr = row0 + w;
@@ -121,7 +136,7 @@ struct GemmLoader {
     }
     // (row within the tile, k-chunk) of this thread's segment q
     __device__ __forceinline__ void seg_of(int w, int q, int& r, int& c) const {
-        if (KSTRIDED) { r = 4 * (w & 31) + q; c = w >> 5; } else { r = w; c = q; }
+        if (KSTRIDED && vec_ok) { r = 4 * (w & 31) + q; c = w >> 5; } else { r = w; c = q; }
     }
     // LDS byte offset of a segment inside an operand image: fragment (row tile, k-step, piece) x 1 KiB, lane (k-half, row % 32) x 16 B
     __device__ __forceinline__ int lds_offset(int w, int q) const {

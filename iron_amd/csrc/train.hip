@@ -1296,6 +1296,31 @@ extern "C" int iron_composite_colocated_backward(float light, const float* dista
 extern "C" int iron_train_last_hip_error(void) { return g_hip_error; }
 extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }  // kept for ABI stability: there is no BLAS any more, always 0
 
+// The layer product of the backward passes on its own (tests, micro-benchmarks): row-major C[m,n] = op(A) op(B) + beta C.
+// op_a / op_b: 0 = as stored ([m,k] / [k,n]), 1 = transposed ([k,m] / [n,k]).  Supported like inside the library: (0,1) forward
+// recompute, (0,0) dX, (1,0) dW (split over K into `workspace` partial tiles when k is large).
+extern "C" size_t iron_train_gemm_workspace_bytes(int32_t op_a, int32_t m, int32_t n) {
+    const size_t partial = op_a ? (size_t)kSplitK * (size_t)m * (size_t)n : 0;   // split-K partial tiles: the dW shape only
+    return (partial + 64 + 12 * 24 * 512) * sizeof(float) + 512;
+}
+
+extern "C" int iron_train_gemm(int32_t op_a, int32_t op_b, int32_t m, int32_t n, int32_t k, const float* A, int32_t lda, const float* B, int32_t ldb,
+                               float beta, float* C, int32_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    if (m < 0 || n < 0 || k < 0 || (op_a && op_b)) return IRON_ERR_BAD_ARG;
+    if (m == 0 || n == 0) return IRON_OK;
+    if (!A || !B || !C || !workspace || workspace_bytes < iron_train_gemm_workspace_bytes(op_a, m, n)) return IRON_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* scratch = partial + (op_a ? (size_t)kSplitK * (size_t)m * (size_t)n : 0);
+    const GemmCtx h{st, scratch, scratch + 64, (size_t)12 * 24 * 512};
+    int rc;
+    if (op_a && !op_b) rc = gemm_dw(h, st, m, n, k, A, B, beta, C, partial);   // A stored [k,m] (ld = m), B [k,n] (ld = n), C [m,n] (ld = n)
+    else rc = gemm_rm(h, op_a != 0, op_b != 0, m, n, k, A, lda, B, ldb, beta, C, ldc);
+    if (rc != IRON_OK) return rc;
+    TR_HIP(hipGetLastError());
+    return IRON_OK;
+}
+
 extern "C" size_t iron_sdf_backward_workspace_bytes(const iron_sdf_train_desc* desc, int64_t n) {
     SdfPlan P;
     if (n < 0 || sdf_plan(desc, n, nullptr, P) != IRON_OK) return 0;
