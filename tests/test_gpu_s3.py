@@ -22,6 +22,7 @@ def s3():
     return {k: v.cuda() for k, v in scenes.build_networks("S3").items()}, golden("g18_S3_trained_like.npz")
 
 
+@torch.no_grad()
 def test_s3_sdf_value_gradient_and_features(s3):
     nets, g = s3
     sdf_net = nets["sdf_network"]
@@ -36,6 +37,7 @@ def test_s3_sdf_value_gradient_and_features(s3):
         assert r64 <= max(floor_abs, 1.5 * floor), (name, r64, floor)
 
 
+@torch.no_grad()
 def test_s3_material_networks(s3):
     nets, g = s3
     pts, nrm, feat = t(g["m_points"]).cuda(), t(g["m_normals"]).cuda(), t(g["m_features"]).cuda()
@@ -47,6 +49,7 @@ def test_s3_material_networks(s3):
         assert r64 <= max(2e-6, 1.5 * floor), (k, r64, floor)
 
 
+@torch.no_grad()
 def test_s3_render_end_to_end(s3):
     nets, g = s3
     cam = Camera(128, 128, t(g["K"]).cuda(), t(g["W2C"]).cuda())
