@@ -62,10 +62,107 @@ def parse():
                     help="skip the untimed extras of the default line (other scaling mode, 8-shard emulation, exact-fp32-core child run)")
     ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c1",
                     help="c1 (default): the BASELINE headline, 800x800 sphere-trace + GGX shade.  c2 / c3 (N=1 only): the other two "
-                         "single-GPU BASELINE configurations, reported in their own units without a roofline object -- "
+                         "single-GPU BASELINE configurations, reported in their own units with the roofline of their dominant kernel and "
+                         "the oracle timed on a bounded sample -- "
                          "c2 = stage-1 NeuS forward, 4096 rays x 128 samples per step; c3 = one stage-2 training step with edge "
                          "sampling at 512x512")
     return ap.parse_args()
+
+
+def _host_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))
+
+
+def _c2_cpu_baseline(threads):
+    """The oracle's NeuS render (torch-CPU port of models/renderer.py:346-453) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import neus_frames
+    from oracle import iron_ref as R
+    from oracle import neus_ref as N
+    from _util import cpu_sd
+    torch.set_num_threads(threads)
+    nets = neus_frames.build_networks(cuda=False)
+    sc = N.NeusScene(cpu_sd(nets["sdf"]), R.SDFSpec(), cpu_sd(nets["color"]), cpu_sd(nets["nerf"]), nets["deviation"].variance.detach().clone(), n_outside=32)
+    n = 2048
+    o, d, near, far = neus_frames.rays(n)
+    with torch.no_grad():
+        N.render(sc, o[:16], d[:16], near[:16], far[:16], cos_anneal_ratio=1.0)
+        t0 = time.perf_counter()
+        N.render(sc, o, d, near, far, cos_anneal_ratio=1.0)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e3, "unit": "krays/s", "cores": threads, "kind": "port",
+            "sample": "%d rays x (64 + 4x16 inside + 32 outside) samples of the same scene, torch-CPU oracle (oracle/neus_ref.py), %.1f s" % (n, dt)}
+
+
+def _c3_cpu_baseline(threads, size=128):
+    """The oracle's stage-2 training step (render with edge sampling under autograd + backward, oracle/train_ref.py) on a bounded
+    sample: the same scene at size x size (a 512x512 step is (512/size)^2 times the rays)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from iron_amd import scenes
+    from oracle import iron_ref as R
+    from oracle import train_ref as T
+    from _util import cpu_sd, tables
+    torch.set_num_threads(threads)
+    names = ("sdf_network", "diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network")
+    nets = scenes.build_networks("S1")
+    sd = {k: T.leaf_state(cpu_sd(nets[k])) for k in names}
+    mt, md = tables()
+    sc = R.Scene(sd["sdf_network"], R.SDFSpec(), {k: (sd[k], R.GGX_SPECS[k]) for k in R.GGX_SPECS}, 32.0, mt, md)
+    K, W2C = scenes.fixture_camera_matrices(size, size)
+    cam = R.CameraSpec(size, size, K, W2C)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        tr = R.raytrace_camera(sc, cam, max_num_rays=50000)
+        dem = (R.sobel_magnitude(tr["depth"]) > 1e-2) & tr["convergent_mask"]
+    res = T.render_camera_edges_train(sc, cam, dem)
+    target = torch.rand(size, size, 3, generator=torch.Generator().manual_seed(1))
+    m = res["convergent_mask"] | res["edge_mask"]
+    (res["color"][m] - target[m]).abs().mean().backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "one training step (trace incl. the mask pre-pass, render with edge sampling under autograd, image loss, backward) of the same "
+                      "scene at %dx%d = 1/%d of the rays of the 512x512 step, torch-CPU oracle (oracle/train_ref.py), %.1f s; no eikonal term, no "
+                      "optimiser" % (size, size, (512 // size) ** 2, dt),
+            "rays_fraction_of_workload": (size / 512.0) ** 2}
+
+
+def _gemm_roofline():
+    """HBM roofline of the backward's dominant kernel, measured here: the layer product Z = X W^T at the shape of one SDF chunk
+    (131 072 rows = 65 536 points x {value, tangent}, 256 -> 256) through iron_train_gemm on the current stream, hipEvents around
+    20 launches.  Algorithmic bytes per launch = A once in + C once out (the 256 KB weight matrix is L2-resident)."""
+    from iron_amd import _lib
+    lib = _lib.load_train()
+    R_, K_, N_ = 131072, 256, 256
+    dev = torch.device("cuda", 0)
+    X = torch.randn(R_, K_, device=dev)
+    W = torch.randn(N_, K_, device=dev) / 16.0
+    out = torch.empty(R_, N_, device=dev)
+    nbytes = lib.iron_train_gemm_workspace_bytes(0, R_, N_)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def launch():
+        rc = lib.iron_train_gemm(0, 1, R_, N_, K_, X.data_ptr(), K_, W.data_ptr(), K_, 0.0, out.data_ptr(), N_, ws.data_ptr(), nbytes, _lib.stream_ptr(dev))
+        assert rc == 0, rc
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        launch()
+    e1.record()
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) / 20 / 1e3
+    bytes_alg = 4.0 * R_ * (K_ + N_)
+    flop = 2.0 * R_ * K_ * N_
+    return {"bound": "hbm", "kernel": "k_gemm_rows<2> (+ k_gemm_pack_b): layer product Z = X W^T, 131072 x 256 x 256, of iron_sdf_backward", "achieved": bytes_alg / sec / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "frac": bytes_alg / sec / 8e12, "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": sec * 1e3, "tflops_fp32_equivalent": flop / sec / 1e12,
+            "note": "bytes = 4 B x rows x (K + N): A read once, C written once; 43 FLOP per byte at K = N = 256 is below the split-fp16 "
+                    "ridge (833 TFLOP/s / 8 TB/s = 104), so HBM is the bound of a layer-wise backward"}
 
 
 def secondary_workload(a):
@@ -77,14 +174,35 @@ def secondary_workload(a):
     _lib.load()
     base = {"n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "roofline": None, "cpu_baseline": None}
+    threads = _host_threads()
     if a.workload == "c2":
         import neus_frames
-        r = neus_frames.run(rays=4096 * a.steps, batches=(4096,), repeats=1)[0]
+        neus_frames.run(rays=4096, batches=(4096,), repeats=1)                      # warm-up
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        r = neus_frames.run(rays=4096 * a.steps, batches=(4096,), repeats=1, warm=False)[0]
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        kernels = {k: {"ms_total": ms, "launches": n, "ms_avg": ms / n} for k, (ms, n) in prof.items() if n}
+        roof = None
+        if "sdf_grad" in kernels:   # get_all at the 128 section mid points of every ray: the dominant kernel of a NeuS batch
+            pts = 4096 * 128
+            sec = kernels["sdf_grad"]["ms_avg"] / 1e3
+            ach = FLOP_SDF_GRAD * pts / sec
+            roof = {"bound": "mfma", "kernel": "k_sdf_grad_h2 (get_all: value + analytic gradient + 256 features at 4096 x 128 points)",
+                    "achieved": ach / 1e12, "peak": PEAK_F16_MFMA / 3.0 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_F16_MFMA / 3.0), "traffic": None,
+                    "flop_per_unit": FLOP_SDF_GRAD, "units_per_launch": pts, "avg_launch_ms": kernels["sdf_grad"]["ms_avg"],
+                    "peak_basis": "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate MAC",
+                    "note": "algorithmic FLOP per point = 2 x (524 544 forward + 459 008 input-gradient) MAC (SURVEY 8d); the kernel evaluates the "
+                            "gradient as three forward-mode tangents (4 wave passes per point), which is not credited"}
         base.update({"metric": "krays/s stage-1 NeuS volume render (models/renderer.py), 4096 rays x 128 samples hierarchical",
                      "value": r["krays_per_s"], "unit": "krays/s", "ms_per_step": round(r["ms"] / a.steps, 3),
                      "config": {"workload": "C2: seeded networks of confs/womask_iron.conf (8x256 SDF, 8-layer PE-10 colour net, NeRF "
                                             "background with 32 outside samples), 4096 rays per step, 64 + 4x16 samples, perturb = 0",
-                                "mlp_points_per_ray": r["mlp_points_per_ray"]}})
+                                "mlp_points_per_ray": r["mlp_points_per_ray"]},
+                     "roofline": roof, "kernels": kernels})
+        if not a.no_cpu_baseline:
+            base["cpu_baseline"] = _c2_cpu_baseline(threads)
     else:
         import train_step
         _lib.load_train()
@@ -94,7 +212,10 @@ def secondary_workload(a):
                      "config": {"workload": "C3: scene S1, render_camera(handle_edges=True, is_training=True), L1 image loss + eikonal "
                                             "term on %d points, backward, Adam on all networks" % r["eikonal_points"],
                                 "hits": r["hits"], "edge_pixels": r["edge_pixels"], "ms_forward_render": r["ms_forward_render"],
-                                "ms_loss_backward": r["ms_loss_backward"], "ms_adam": r["ms_adam"]}})
+                                "ms_loss_backward": r["ms_loss_backward"], "ms_adam": r["ms_adam"]},
+                     "roofline": _gemm_roofline()})
+        if not a.no_cpu_baseline:
+            base["cpu_baseline"] = _c3_cpu_baseline(threads)
     print(json.dumps(base))
 
 
