@@ -222,7 +222,7 @@ struct Ring {
     }
 };
 
-// this wave's 8 LDS-DMA instructions of one slot (global_load_lds; the buffer-addressed form measured no faster).
+// this wave's 8 LDS-DMA instructions of one slot (global_load_lds; the buffer-addressed form, raw_ptr_buffer_load_lds, measured no faster).
 // The CU's texture-address path moves 64 B/clk, so the 32 KiB of a hidden slot hold all four waves ~500 cycles: a wave
 // does not run ahead of its LDS-DMA instructions (issuing them one by one behind MFMAs, or staggered over the waves,
 // costs 90-170 cycles apiece instead of ~60 in a burst; both measured).
@@ -245,22 +245,6 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
             const int f = wave + 4 * i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
                                              (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
-        }
-    }
-    return;
-    if (hidden) {  // 32 fragments of 1 KiB; this wave moves fragments wave, wave+4, ...
-#pragma unroll
-        for (int i = 0; i < kLoadsPerSlot; ++i) {
-            const int f = wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 1024), 16,
-                                                     lane * 16, (int)(src.off + f * 1024), 0, 0);
-        }
-    } else {       // head slot: 8 KiB as 32 pieces of 256 B
-#pragma unroll
-        for (int i = 0; i < kLoadsPerSlot; ++i) {
-            const int f = wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)(wr + f * 256), 4,
-                                                     lane * 4, (int)(src.off + f * 256), 0, 0);
         }
     }
 }

@@ -260,13 +260,15 @@ class Camera(object):
         return torch.from_numpy(np.stack((u, v), axis=-1).astype(np.float32)).to(self.device) + 0.5
 
     def project(self, points):
-        """points [...,3] -> uv [...,2] (raytracer.py:305-325); tiny torch expression, any device."""
+        """points [...,3] -> uv [...,2] (raytracer.py:305-325): homogeneous point through W2C and K, perspective division.  Written
+        as broadcast products and sums (4-term dot products; differentiable): a [n,4] x [4,4] torch.matmul would go to a BLAS
+        library for 16 multiply-adds per point."""
         sh = list(points.shape[:-1])
         p = points.reshape(-1, 3)
-        p = torch.cat([p, torch.ones_like(p[:, :1])], dim=1)
-        uv = torch.matmul(torch.matmul(p, self.W2C.transpose(1, 0)), self.K.transpose(1, 0))
-        uv = uv[:, :2] / uv[:, 2:3]
-        return uv.view(sh + [2])
+        ph = torch.cat([p, torch.ones_like(p[:, :1])], dim=1)
+        cam = (ph.unsqueeze(1) * self.W2C.unsqueeze(0)).sum(dim=-1)
+        img = (cam.unsqueeze(1) * self.K.unsqueeze(0)).sum(dim=-1)
+        return (img[:, :2] / img[:, 2:3]).view(sh + [2])
 
     def _crop_origin(self, trgt_W, trgt_H, center_crop, ul_corner):
         """(column, row) of the crop window's upper-left pixel.  The random draws consume numpy's global generator exactly
@@ -609,7 +611,7 @@ def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_
     # the edge point slides along its normal with the parameters, and so does its projection
     moving = reparam_points(anchor, g, unit, sdf_at_edge)
     moving_uv = camera.project(moving)
-    in_plane = (unit @ camera.W2C[:3, :3].t())[:, :2]
+    in_plane = (unit.unsqueeze(1) * camera.W2C[:2, :3].unsqueeze(0)).sum(dim=-1)   # first two rows of the camera-space normal
     in_plane = in_plane / (in_plane.norm(dim=-1, keepdim=True) + 1e-10)
     offset = PIXEL_RADIUS * in_plane
     n_edge = anchor.shape[0]

@@ -387,7 +387,10 @@ def test_edge_pixel_backward_with_the_oracles_edge_points():
     from oracle import train_ref as T
     g = golden("g15_train_edges_S1.npz")
     mt, md = tables()
-    wt, em = t(g["loss_weights"]), t(g["edge_mask"]).bool()
+    # the edge pixels whose blend-weight gradient is decided by rounding (un-walked candidates sitting on torch.clamp's corner, grazing
+    # side rays, ...: make_golden_train.py --stable, see test_g15s_...) are left out of the loss: with them in, the oracle run on another
+    # host CPU disagrees with itself by per cent
+    wt, em = t(g["loss_weights"]), t(g["edge_mask"]).bool() & t(golden("g15s_train_edges_stable_S1.npz")["stable_pixel_mask"]).bool()
     cpu_nets = scenes.build_networks("S1")
     sd = {k: T.leaf_state(cpu_sd(cpu_nets[k])) for k in NETS}
     sc = R.Scene(sd["sdf_network"], R.SDFSpec(), {k: (sd[k], R.GGX_SPECS[k]) for k in R.GGX_SPECS}, golden_meta()["light"], mt, md)
