@@ -18,10 +18,17 @@
 #pragma once
 #include "iron_common.h"
 #include "mlp_core.h"
+#include "lds_dma.h"
 
 // build-time switches (tools/variants.py A/B arms; IRON_H2_NO_DMA / IRON_H2_NO_BARRIER are timing experiments only)
 #ifndef IRON_H2_STAMP
 #define IRON_H2_STAMP 0   // diagnostic build: s_memtime stamps of one evaluation's ring steps (tools/stamps.py)
+#endif
+#ifndef IRON_H2_ASM_DMA
+#define IRON_H2_ASM_DMA 0      // 1: LDS-DMA from inline assembly (lds_dma.h: exact lgkmcnt waits); measured level with the builtin
+#endif
+#ifndef IRON_H2_FRAG_AHEAD
+#define IRON_H2_FRAG_AHEAD 1   // k-steps of A fragments in flight in step_hidden (2 with ASM_DMA 1: no gain)
 #endif
 #ifndef IRON_H2_RING_AHEAD
 #define IRON_H2_RING_AHEAD 3
@@ -232,19 +239,30 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
 #endif
     const int lane = threadIdx.x & 63;
     const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
+#if IRON_H2_ASM_DMA
+    const uint32_t wr_lds = lds_addr_of(wr);
+#endif
     if (hidden) {
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
+#if IRON_H2_ASM_DMA
+            lds_dma16(gsrc + f * 1024, wr_lds + f * 1024);
+#else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
                                              (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+#endif
         }
     } else {
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
+#if IRON_H2_ASM_DMA
+            lds_dma4(gsrc + f * 256, wr_lds + f * 256);
+#else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
                                              (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+#endif
         }
     }
 }
@@ -427,7 +445,11 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
                                             const f32x16& p_hi, const f32x16& p_lo, TileFrag& out_prev, f32x16& hf_prev,
                                             unsigned long long* rec = nullptr) {
     if (add_bias) acc_hi = lds_half_tile(bias, tile, lane >> 5);
-    half8 fh = lds_frag(rd, 0, lane), fl = lds_frag(rd, 1, lane);
+    // A fragments: kFragAhead k-steps in flight (static register sets f*[ks % (kFragAhead + 1)] after unrolling)
+    constexpr int kFragAhead = IRON_H2_FRAG_AHEAD, kSets = kFragAhead + 1;
+    half8 fhs[kSets], fls[kSets];
+#pragma unroll
+    for (int a = 0; a < kFragAhead; ++a) { fhs[a] = lds_frag(rd, 2 * a, lane); fls[a] = lds_frag(rd, 2 * a + 1, lane); }
     __builtin_amdgcn_sched_barrier(0);
     dma_issue(src, wr, src_hidden, wave);
     __builtin_amdgcn_sched_barrier(0);
@@ -441,11 +463,11 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     EpiState es;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        half8 nh = fh, nl = fl;
-        if (ks < 15) {  // next k-step's fragments: in flight while this step's MFMAs run
-            nh = lds_frag(rd, 2 * ks + 2, lane);
-            nl = lds_frag(rd, 2 * ks + 3, lane);
+        if (ks + kFragAhead < 16) {  // fragments of k-step ks + kFragAhead: in flight while this and the next steps' MFMAs run
+            fhs[(ks + kFragAhead) % kSets] = lds_frag(rd, 2 * (ks + kFragAhead), lane);
+            fls[(ks + kFragAhead) % kSets] = lds_frag(rd, 2 * (ks + kFragAhead) + 1, lane);
         }
+        const half8 fh = fhs[ks % kSets], fl = fls[ks % kSets];
         const int ti = ks >> 1, s = ks & 1;
         acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
@@ -453,8 +475,6 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
         if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
-        fh = nh;
-        fl = nl;
         if constexpr (CARRY) {
             static_assert(!CARRY || EPI == 1, "a carried tile ends as split fragments");
             if (ks == 12) {

@@ -282,7 +282,8 @@ int create_sdf(iron_net* net, const iron_linear* L, hipStream_t st) {
     s.scale = d.scale;
     s.n_hidden_layers = nl - 1;
     s.skip_layer = skip;
-    return build_h2_sdf(net, L, scale_base, soff, st);
+    { const int rc_h2 = build_h2_sdf(net, L, scale_base, soff, st); if (rc_h2 != IRON_OK) return rc_h2; }
+    return build_w16_sdf(net, L, scale_base, soff, st);
 }
 
 int create_render(iron_net* net, const iron_linear* L, hipStream_t st) {
@@ -516,6 +517,7 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
     if (rc != IRON_OK) {
         if (net->blob) (void)hipFree(net->blob);
         if (net->h2_blob) (void)hipFree(net->h2_blob);
+        if (net->w16_blob) (void)hipFree(net->w16_blob);
         delete net;
         return rc;
     }
@@ -527,6 +529,7 @@ extern "C" int iron_net_destroy(iron_net_t* net) {
     if (!net) return IRON_OK;
     if (net->blob) IRON_HIP_TRY(hipFree(net->blob));
     if (net->h2_blob) IRON_HIP_TRY(hipFree(net->h2_blob));
+    if (net->w16_blob) IRON_HIP_TRY(hipFree(net->w16_blob));
     delete net;
     return IRON_OK;
 }

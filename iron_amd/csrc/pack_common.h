@@ -32,6 +32,7 @@ __global__ void k_pack_bias(float* __restrict__ dst, const float* __restrict__ b
 __global__ void k_pack_row(float* __restrict__ dst, PackSrc s, int row, int col_off, int cols_valid);
 
 int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st);
+int build_w16_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st);
 int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, const HeadSrcs& hs,
                     int head_w, hipStream_t st);
 

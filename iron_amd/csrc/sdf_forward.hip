@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64, 1) void k_sdf_full(SdfNetDev net, const float* 
 
 namespace iron {
 int launch_sdf_values_h2(const iron_net* net, const float* x, int64_t n, float* out, hipStream_t st);
+int launch_sdf_values_w16(const iron_net* net, const float* x, int64_t n, float* out, hipStream_t st);
+bool use_w16_core();
 }
 
 using namespace iron;
@@ -82,6 +84,7 @@ extern "C" int iron_sdf_forward(const iron_net_t* net, const float* x, int64_t n
     const int64_t n_tiles = (n + kTile - 1) / kTile;
     if (((uintptr_t)x & 3) || ((uintptr_t)out & 3)) return IRON_ERR_BAD_ARG;
     ProfScope ps(IRON_PROF_SDF_FORWARD, st);
+    if (out_cols == 1 && use_w16_core() && net->w16_blob) return launch_sdf_values_w16(net, x, n, out, st);
     if (out_cols == 1 && h2_sdf_usable(net)) return launch_sdf_values_h2(net, x, n, out, st);
     if (out_cols == 1) {
         hipLaunchKernelGGL(k_sdf_values, dim3(grid_for_tiles(n_tiles)), dim3(64), 0, st, net->sdf, x, n, out, 1);
