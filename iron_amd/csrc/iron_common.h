@@ -124,6 +124,8 @@ struct iron_net {
     void* h2_blob;        // h2 (split-fp16) stream, SDF nets
     iron::H2StreamDev h2_trace;  // hidden stack only
     iron::H2StreamDev h2_full;   // + the feature rows of the last layer
+    void* h2_scratch;     // material nets with a skip layer on the h2 core: partial sums parked between layer 0 and the skip layer
+    size_t h2_scratch_floats;
     void* w16_blob;       // stream of the 8-wave w16 core (w16.hip), SDF nets of the reference shape
     iron::H2StreamDev w16_trace;
     int device;

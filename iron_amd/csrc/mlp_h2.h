@@ -513,10 +513,14 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
 // CARRY: in[7] is still pending as the accumulators (c_hi, c_lo) the previous layer DEFERred; its epilogue runs under
 // this layer's first tile (step_hidden<CARRY>).  DEFER: this layer's tile 7 is handed on the same way (out[7] is then
 // not written here).
-template <bool FAST, bool HEAD, bool LAST, int ACT = 0, bool CARRY = false, bool DEFER = false>
+// HEAD = 2: the head product is two ring slots (hd, *hd2: head slots 0..23 and 24..47).  INIT: every tile's pre-activation sum
+// starts from bias + init[tile][16][64] (f32, this lane's column: partial sums another product left in global memory).
+template <bool FAST, int HEAD, bool LAST, int ACT = 0, bool CARRY = false, bool DEFER = false, bool INIT = false>
 __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, const HeadFrag& hd, int lane,
                                                 TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
-                                                f32x16 (&hf)[kHidTiles], f32x16& c_hi, f32x16& c_lo) {
+                                                f32x16 (&hf)[kHidTiles], f32x16& c_hi, f32x16& c_lo,
+                                                const HeadFrag* hd2 = nullptr, const float* __restrict__ init = nullptr) {
+    static_assert(!INIT || HEAD > 0, "the partial sums are added on top of the head product");
     static_assert(!(LAST && DEFER), "the last layer ends in f32 tiles");
     const int wave = ring.wave;
     f32x16 acc[2][2];  // [tile parity][hi, lo]: the epilogue of tile t-1 overlaps the MFMAs of tile t
@@ -527,10 +531,22 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
         constexpr int P = (TO) & 1, Q = P ^ 1;                                                                             \
         acc[P][0] = zero16();                                                                                              \
         acc[P][1] = zero16();                                                                                              \
-        if constexpr (HEAD) {                                                                                              \
+        f32x16 part;                                                                                                       \
+        if constexpr (INIT) {                                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) part[r] = init[((TO) * 16 + r) * 64 + lane];                    \
+        }                                                                                                                  \
+        if constexpr (HEAD >= 1) {                                                                                         \
             ring.sync();                                                                                                   \
             const RingStep sh = ring.step();                                                                               \
             step_head(sh.rd, bias, sh.wr, sh.src, sh.hidden, wave, lane, TO, true, hd, acc[P][0], acc[P][1]);              \
+        }                                                                                                                  \
+        if constexpr (HEAD >= 2) {                                                                                         \
+            ring.sync();                                                                                                   \
+            const RingStep sh = ring.step();                                                                               \
+            step_head(sh.rd, bias, sh.wr, sh.src, sh.hidden, wave, lane, TO, false, *hd2, acc[P][0], acc[P][1]);           \
+        }                                                                                                                  \
+        if constexpr (INIT) {                                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[P][0][r] += part[r];                                        \
         }                                                                                                                  \
         ring.sync();                                                                                                       \
         const RingStep st = ring.step();                                                                                   \

@@ -37,7 +37,8 @@ __global__ void k_pack_h2_hidden(_Float16* __restrict__ dst, PackSrc s, int to, 
 }
 
 // dst: one head slot (8 KiB): fragments [ks 0..2][piece][lane][j] + 2 KiB of zero padding
-__global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs hs, int to) {
+// slot_off: first head slot of this ring slot (a head wider than 24 slots is streamed as two ring slots: 0 and 24)
+__global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs hs, int to, int slot_off) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks 0..3, lane, j)
     if (e >= 4 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -45,7 +46,7 @@ __global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs h
     const int row = 32 * to + i;
     float w = 0.0f;
     if (ks < kHeadKSteps) {
-        const int slot = 8 * ks + j;
+        const int slot = slot_off + 8 * ks + j;
         for (int k = 0; k < hs.n; ++k) {
             const int local = slot - hs.slot_base[k];
             if (local >= 0 && local < head_slots(hs.levels[k])) {
@@ -119,7 +120,7 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     size_t q = 0;
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
     for (int to = 0; to < kHidTiles; ++to, ++q)
-        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to);
+        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to, 0);
     for (int l = 1; l <= nl - 2; ++l) {
         const bool is_skip = (l == skip);
         const float mul = is_skip ? kInvSqrt2 : 1.0f;
@@ -128,7 +129,7 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
             if (is_skip) {
                 HeadSrcs h2 = hs;
                 h2.col_off[0] = kHidden - pe;
-                hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, to);
+                hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, to, 0);
                 ++q;
             }
             hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), to, 0, cols_valid);
@@ -160,23 +161,34 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     return h2_overflow_check(net);
 }
 
-// h2 stream of a material network.  Sequence: layer 0: per output tile [head slot][hidden slot = feature part];
-// layers 1..n-2: hidden slots.  Side blocks: biases of layers 0..n-2, rows 0..d_out-1 of the last layer.
+// h2 stream of a material network.  Sequence (= memory order):
+//   [skip nets only: 8 hidden slots = the FEATURE columns of the skip layer (x 1/sqrt(2)); the kernel multiplies them while the
+//    features are still its live input and parks the partial sums in net->h2_scratch until the skip layer]
+//   layer 0: per output tile [head slot(s)][hidden slot = feature part];
+//   layers 1..n-2: per output tile [skip layer: head slot(s) of its head columns] hidden slot (skip layer: its x columns).
+// A head of up to 24 slots is one ring slot, up to 48 (the stage-1 colour net: PE-10 points + PE-4 view + normals) two.
+// Side blocks: biases of layers 0..n-2, rows 0..d_out-1 of the last layer.
 int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, const HeadSrcs& hs,
                     int head_w, hipStream_t st) {
     const iron_net_desc& d = net->desc;
     const int nl = d.n_linear;
-    // the h2 material kernels are built for skip-free nets whose head fits three 16-deep k-steps (24 slots); anything
-    // else (the stage-1 colour net: 48 head slots, skip at layer 4) keeps only its fp32 pack
+    const int skip = d.skip_layer;
     int head_slots_total = 0;
     for (int k = 0; k < hs.n; ++k) head_slots_total += head_slots(hs.levels[k]);
-    if (d.skip_layer != -1 || head_slots_total > kHeadSlots) return IRON_OK;
+    if (head_slots_total > 2 * kHeadSlots) return IRON_OK;   // fp32 pack only
+    const int n_head = head_slots_total > kHeadSlots ? 2 : 1;
+    // kernels exist for (one head slot, no skip) and (two head slots, skip at a hidden layer): shade.hip launch_material
+    if ((n_head == 2) != (skip != -1)) return IRON_OK;
     std::vector<uint32_t> table;
     size_t off = 0;
     auto add = [&](int kind) { table.push_back((uint32_t)off); table.push_back((uint32_t)kind); off += kind ? kSlotBytes : 8192; };
-    for (int to = 0; to < kHidTiles; ++to) { add(0); add(1); }
+    if (skip != -1) for (int to = 0; to < kHidTiles; ++to) add(1);
+    for (int to = 0; to < kHidTiles; ++to) { for (int h = 0; h < n_head; ++h) add(0); add(1); }
     for (int l = 1; l <= nl - 2; ++l)
-        for (int to = 0; to < kHidTiles; ++to) add(1);
+        for (int to = 0; to < kHidTiles; ++to) {
+            if (l == skip) for (int h = 0; h < n_head; ++h) add(0);
+            add(1);
+        }
     const uint32_t n_slots = (uint32_t)(table.size() / 2);
     if (n_slots > 127 || nl - 1 > 8) return IRON_ERR_UNSUPPORTED;
     const size_t table_off = (off + 255) & ~(size_t)255;
@@ -189,15 +201,31 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
     char* base = (char*)net->h2_blob;
     size_t q = 0;
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
+    if (skip != -1) {   // feature columns of the skip layer: [x 256 | head inputs | features 256] / sqrt(2)
+        const PackSrc ps = make_pack_src(L[skip], scale_base + soff[skip], kHidden, 0, kInvSqrt2);
+        for (int to = 0; to < kHidTiles; ++to, ++q)
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, kHidden + head_w, kHidden);
+    }
     for (int to = 0; to < kHidTiles; ++to) {
-        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to);
-        ++q;
-        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), to, head_w, kHidden);
+        const PackSrc ps = make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f);
+        for (int h = 0; h < n_head; ++h, ++q)
+            hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hs, to, h * kHeadSlots);
+        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, head_w, kHidden);
         ++q;
     }
-    for (int l = 1; l <= nl - 2; ++l)
-        for (int to = 0; to < kHidTiles; ++to, ++q)
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f), to, 0, kHidden);
+    for (int l = 1; l <= nl - 2; ++l) {
+        const bool is_skip = (l == skip);
+        const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], kHidden, 0, is_skip ? kInvSqrt2 : 1.0f);
+        HeadSrcs hs2 = hs;
+        for (int k = 0; k < hs2.n; ++k) hs2.col_off[k] += kHidden;
+        for (int to = 0; to < kHidTiles; ++to) {
+            if (is_skip)
+                for (int h = 0; h < n_head; ++h, ++q)
+                    hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hs2, to, h * kHeadSlots);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
+            ++q;
+        }
+    }
     for (int l = 0; l <= nl - 2; ++l)
         hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, kHidden);
     const iron_linear& last = L[nl - 1];
@@ -213,7 +241,15 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
         if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
     net->h2_trace = s;
     net->h2_full = s;
-    return h2_overflow_check(net);
+    if (skip != -1) {   // partial sums of the skip layer: one 32 KiB tile set per wave of a full grid
+        hipDeviceProp_t prop;
+        IRON_HIP_TRY(hipGetDeviceProperties(&prop, net->device));
+        net->h2_scratch_floats = (size_t)prop.multiProcessorCount * 4 * kHidTiles * 16 * 64;
+        IRON_HIP_TRY(hipMalloc(&net->h2_scratch, net->h2_scratch_floats * sizeof(float)));
+    }
+    const int rc = h2_overflow_check(net);
+    if (!net->h2_blob && net->h2_scratch) { (void)hipFree(net->h2_scratch); net->h2_scratch = nullptr; }
+    return rc;
 }
 
 }  // namespace iron

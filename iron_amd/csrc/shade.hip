@@ -593,6 +593,117 @@ __global__ __launch_bounds__(256, 1) void k_material_h2(H2StreamDev hs, RenderNe
     ring.drain();
 }
 
+// RenderingNetwork.forward on the h2 core for a net with a WIDE head (25..48 slots: two head ring slots) and a SKIP connection at
+// a hidden layer (models/fields.py:222-223) -- the stage-1 colour net of confs/womask_iron.conf (PE-10 points, PE-4 view, normals;
+// 8 layers, skip_in = [4]).  The skip layer's input is [x | head inputs | features] / sqrt(2); its feature product is taken FIRST,
+// while the features are the live input set, and its partial sums wait in `scratch` ([block][wave][8 tiles][16][64] f32, written and
+// read back by the same lane) until the skip layer starts its accumulators from them: no third activation set in registers.
+// Stream order: pack_h2.hip build_h2_render.
+template <int LP, int LV, bool HAS_VIEW, bool HAS_NRM>
+__global__ __launch_bounds__(256, 1) void k_material_h2_skip(H2StreamDev hs, RenderNetDev net, MatArgs a, float* __restrict__ scratch) {
+    static_assert(HeadCfg<LP, LV, HAS_VIEW, HAS_NRM>::kSlots > kHeadSlots && HeadCfg<LP, LV, HAS_VIEW, HAS_NRM>::kSlots <= 2 * kHeadSlots, "two head slots");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds = smem;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Ring ring;
+    h2_setup(hs, lds, ring);
+    float* part = scratch + ((size_t)blockIdx.x * 4 + wave) * (kHidTiles * 16 * 64);
+    const int count = a.count_ptr ? *a.count_ptr : a.count;
+    const int n_tiles = (count + kTile - 1) / kTile;
+    const int n_groups = (n_tiles + 3) / 4;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int tile = g * 4 + wave;
+        const int li = tile * kTile + (lane & 31);
+        const bool ok = li < count;
+        const int pi = ok ? (a.list ? a.list[li] : li) : 0;
+        const int ai = ok ? (a.list_order_aux ? li : pi) : 0;
+        float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 1.f, vx = 0.f, vy = 0.f, vz = 0.f;
+        if (ok) {
+            px = a.points[3 * (size_t)pi]; py = a.points[3 * (size_t)pi + 1]; pz = a.points[3 * (size_t)pi + 2];
+            if (a.normals) { nx = a.normals[3 * (size_t)ai]; ny = a.normals[3 * (size_t)ai + 1]; nz = a.normals[3 * (size_t)ai + 2]; }
+            if (a.normalise) {
+                const float nn = sqrtf((nx * nx + ny * ny) + nz * nz) + 1e-10f;
+                nx = nx / nn; ny = ny / nn; nz = nz / nn;
+            }
+            if (a.neg_normal_view) { vx = -nx; vy = -ny; vz = -nz; }
+            else if (a.view) { vx = a.view[3 * (size_t)ai]; vy = a.view[3 * (size_t)ai + 1]; vz = a.view[3 * (size_t)ai + 2]; }
+        }
+        HeadFrag hd, hd2;
+        {
+            float head[2 * kHeadSlots];
+#pragma unroll
+            for (int i = 0; i < 2 * kHeadSlots; ++i) head[i] = 0.0f;
+            int base = 0;
+            head_fill<LP>(px, py, pz, half, head + base);
+            base += head_slots(LP);
+            if constexpr (HAS_VIEW) { head_fill<LV>(vx, vy, vz, half, head + base); base += head_slots(LV); }
+            if constexpr (HAS_NRM) { head_fill<0>(nx, ny, nz, half, head + base); base += 2; }
+            split_head(head, hd);
+            split_head(head + kHeadSlots, hd2);
+        }
+        TileFrag in[kHidTiles], out[kHidTiles];
+        f32x16 hf[kHidTiles];
+        {   // features -> split fragments
+            const bool tile_ok = tile < n_tiles;
+            const float* src = (a.feat_packed && tile_ok) ? a.feat_packed + (size_t)tile * kSBufFloats : nullptr;
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                f32x16 v = zero16();
+                if (src) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = src[(t * 16 + r) * 64 + lane];
+                } else if (a.feat_rows && ok) {
+                    const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w4 = row[(32 * t + 8 * q + 4 * half) >> 2];
+                        v[4 * q] = w4.x; v[4 * q + 1] = w4.y; v[4 * q + 2] = w4.z; v[4 * q + 3] = w4.w;
+                    }
+                }
+                split_tile(v, out[t]);
+            }
+        }
+        // the skip layer's feature product (8 hidden slots, no bias, no activation) -> scratch
+        {
+            TileFrag dummy_out;
+            f32x16 dummy_hf;
+#define IRON_PTILE(TO)                                                                                                   \
+    {                                                                                                                    \
+        ring.sync();                                                                                                     \
+        const RingStep st = ring.step();                                                                                 \
+        f32x16 a_hi = zero16(), a_lo = zero16();                                                                         \
+        step_hidden<true, 0, 1>(st.rd, lds + kLdsBias, st.wr, st.src, st.hidden, wave, lane, TO, false, out, a_hi, a_lo, \
+                                a_hi, a_lo, dummy_out, dummy_hf, st.rec);                                                \
+        const f32x16 z = h2_combine(a_hi, a_lo);                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) part[((TO) * 16 + r) * 64 + lane] = z[r];                         \
+    }
+            IRON_PTILE(0) IRON_PTILE(1) IRON_PTILE(2) IRON_PTILE(3) IRON_PTILE(4) IRON_PTILE(5) IRON_PTILE(6) IRON_PTILE(7)
+#undef IRON_PTILE
+        }
+        // `out` holds the features; the sets alternate as layer input / output.  The launcher admits 8 relu layers with the
+        // skip at layer 4:  l0 out->in, l1 in->out, l2 out->in, l3 in->out, l4 (skip) out->in, l5 in->out, l6 out->in, l7 in->hf
+        f32x16 c_hi, c_lo;
+        const char* bias = lds + kLdsBias;
+        h2_hidden_layer<true, 2, false, 1, false, true>(ring, bias, hd, lane, out, in, hf, c_hi, c_lo, &hd2);
+        h2_hidden_layer<true, 0, false, 1, true, true>(ring, bias + 1 * 1024, hd, lane, in, out, hf, c_hi, c_lo);
+        h2_hidden_layer<true, 0, false, 1, true, true>(ring, bias + 2 * 1024, hd, lane, out, in, hf, c_hi, c_lo);
+        h2_hidden_layer<true, 0, false, 1, true, true>(ring, bias + 3 * 1024, hd, lane, in, out, hf, c_hi, c_lo);
+        h2_hidden_layer<true, 2, false, 1, true, true, true>(ring, bias + 4 * 1024, hd, lane, out, in, hf, c_hi, c_lo, &hd2, part);
+        h2_hidden_layer<true, 0, false, 1, true, true>(ring, bias + 5 * 1024, hd, lane, in, out, hf, c_hi, c_lo);
+        h2_hidden_layer<true, 0, false, 1, true, true>(ring, bias + 6 * 1024, hd, lane, out, in, hf, c_hi, c_lo);
+        h2_hidden_layer<true, 0, true, 1, true, false>(ring, bias + 7 * 1024, hd, lane, in, out, hf, c_hi, c_lo);
+        for (int c = 0; c < net.d_out; ++c) {
+            float v = row_dot_lds(lds + kLdsRows + c * 1024, hf, half) + net.b_last[c];
+            v = net.output_scale * (v + net.output_bias);  // fields.py:235
+            if (net.squeeze_out) v = net.squeeze_out_scale * (1.0f / (1.0f + expf(-v)));  // fields.py:236-237
+            if (ok && lane < 32) a.out[(size_t)li * net.d_out + c] = v;
+        }
+    }
+    ring.drain();
+}
+
 // ---- hit list + final pointwise stage ---------------------------------------------------------------
 __global__ void k_compact(const uint8_t* __restrict__ conv, int n, int* __restrict__ count, int* __restrict__ list) {
     const int stride = gridDim.x * blockDim.x;
@@ -794,7 +905,22 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
     const int lp = d.multires > 0 ? d.multires : 0;
     const int lv = d.multires_view > 0 ? d.multires_view : 0;
     ProfScope ps(IRON_PROF_MATERIAL, st);
-    if (use_h2_core() && net->h2_blob && r.n_hidden_layers >= 2 && r.n_hidden_layers % 2 == 0) {
+    if (use_h2_core() && net->h2_blob && net->h2_scratch && r.skip_layer == 4 && r.n_hidden_layers == 8 && d.mode == IRON_MODE_IDR &&
+        lp == 10 && lv == 4) {   // the stage-1 colour net (confs/womask_iron.conf)
+        static bool attr4 = false;
+        if (!attr4) {
+            IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_material_h2_skip<10, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total));
+            attr4 = true;
+        }
+        const int64_t groups = (max_tiles + 3) / 4;
+        const int64_t cap = (int64_t)(net->h2_scratch_floats / (4 * kHidTiles * 16 * 64));   // blocks the scratch was sized for
+        const unsigned g2 = (unsigned)(groups < cap ? (groups > 0 ? groups : 1) : cap);
+        hipLaunchKernelGGL((k_material_h2_skip<10, 4, true, true>), dim3(g2), dim3(256), kLdsH2Total, st, net->h2_trace, r, a,
+                           (float*)net->h2_scratch);
+        IRON_HIP_TRY(hipGetLastError());
+        return IRON_OK;
+    }
+    if (use_h2_core() && net->h2_blob && r.skip_layer == -1 && r.n_hidden_layers >= 2 && r.n_hidden_layers % 2 == 0) {
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)k_material_h2<0, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
