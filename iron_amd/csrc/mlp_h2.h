@@ -400,9 +400,9 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
         if (ks == 6) { _Pragma("unroll") for (int i = 8 + a8; i < 8 + b8; ++i) { st.e[i] = __builtin_amdgcn_logf(st.e[i]); pin1(st.e[i]); } }
         if (ks == 7) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
         if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = __builtin_fmaf(st.e[i], kC2, st.z[i]); pin1(st.z[i]); } }
-    } else {
+    } else if constexpr (ACT == 1) {
         if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
-    }
+    }   // ACT == 2: identity (a linear layer)
     if constexpr (EPI == 1) {
         if (ks == 9) {
             _Pragma("unroll") for (int q = a8; q < b8; ++q) {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
 // EPI: 0 = nothing pending, 1 = pending tile -> split fragments, 2 = pending tile -> f32 tile (last layer).
 // rd / bias / wr are distinct LDS regions (see the note above): __restrict__ is what lets the reads proceed
 // while the refill is in flight.
-// ACT: 0 = softplus(beta=100) (SDF net), 1 = relu (material nets).
+// ACT: 0 = softplus(beta=100) (SDF net), 1 = relu (material nets), 2 = identity (NeRF feature_linear).
 // CARRY (with EPI = 1): the pending tile is tile 7 of the PREVIOUS layer, i.e. this layer's own input in[7].  Its
 // fragments leave the pipeline behind k-step 12 and are first multiplied in k-step 14, so the last tile of a layer
 // gets the same hidden epilogue as the other seven instead of an exposed one at the layer boundary.
@@ -515,7 +515,9 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
 // not written here).
 // HEAD = 2: the head product is two ring slots (hd, *hd2: head slots 0..23 and 24..47).  INIT: every tile's pre-activation sum
 // starts from bias + init[tile][16][64] (f32, this lane's column: partial sums another product left in global memory).
-template <bool FAST, int HEAD, bool LAST, int ACT = 0, bool CARRY = false, bool DEFER = false, bool INIT = false>
+// NT: number of output tiles (8; 4 for a 128-wide layer: its slots' rows 128..255 are never streamed).
+// A CARRYing layer finishes the previous layer's last tile with ITS OWN ACT: only layers of equal ACT may be chained by DEFER/CARRY.
+template <bool FAST, int HEAD, bool LAST, int ACT = 0, bool CARRY = false, bool DEFER = false, bool INIT = false, int NT = kHidTiles>
 __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, const HeadFrag& hd, int lane,
                                                 TileFrag (&in)[kHidTiles], TileFrag (&out)[kHidTiles],
                                                 f32x16 (&hf)[kHidTiles], f32x16& c_hi, f32x16& c_lo,
@@ -527,7 +529,7 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
     TileFrag dummy_out;
     f32x16 dummy_hf;
 #define IRON_H2_TILE(TO)                                                                                                   \
-    {                                                                                                                      \
+    if constexpr ((TO) < NT) {                                                                                             \
         constexpr int P = (TO) & 1, Q = P ^ 1;                                                                             \
         acc[P][0] = zero16();                                                                                              \
         acc[P][1] = zero16();                                                                                              \
@@ -566,15 +568,19 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
     IRON_H2_TILE(0) IRON_H2_TILE(1) IRON_H2_TILE(2) IRON_H2_TILE(3)
     IRON_H2_TILE(4) IRON_H2_TILE(5) IRON_H2_TILE(6) IRON_H2_TILE(7)
 #undef IRON_H2_TILE
+    static_assert(NT % 2 == 0 && NT >= 2 && NT <= kHidTiles, "the last tile sits in accumulator set 1");
     if constexpr (DEFER) {
         c_hi = acc[1][0];
         c_lo = acc[1][1];
     } else if constexpr (ACT == 0) {
-        if constexpr (LAST) hf[kHidTiles - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
-        else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[kHidTiles - 1]);
+        if constexpr (LAST) hf[NT - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
+        else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[NT - 1]);
+    } else if constexpr (ACT == 1) {
+        if constexpr (LAST) hf[NT - 1] = relu_tile(h2_combine(acc[1][0], acc[1][1]));
+        else split_tile(relu_tile(h2_combine(acc[1][0], acc[1][1])), out[NT - 1]);
     } else {
-        if constexpr (LAST) hf[kHidTiles - 1] = relu_tile(h2_combine(acc[1][0], acc[1][1]));
-        else split_tile(relu_tile(h2_combine(acc[1][0], acc[1][1])), out[kHidTiles - 1]);
+        if constexpr (LAST) hf[NT - 1] = h2_combine(acc[1][0], acc[1][1]);
+        else split_tile(h2_combine(acc[1][0], acc[1][1]), out[NT - 1]);
     }
 }
 

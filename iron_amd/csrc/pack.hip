@@ -493,7 +493,7 @@ int create_nerf(iron_net* net, const iron_linear* L, hipStream_t st) {
     r.skip_after = skip;
     r.levels = lp;
     r.levels_view = lv;
-    return IRON_OK;
+    return build_h2_nerf(net, L, scale_base, soff, st);
 }
 
 }  // namespace

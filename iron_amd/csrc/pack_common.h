@@ -36,4 +36,6 @@ int build_w16_sdf(iron_net* net, const iron_linear* L, const float* scale_base, 
 int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, const HeadSrcs& hs,
                     int head_w, hipStream_t st);
 
+int build_h2_nerf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st);
+
 }  // namespace iron

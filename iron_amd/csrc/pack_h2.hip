@@ -59,6 +59,26 @@ __global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs h
     store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
 }
 
+// head slot of a 4-component source (NeRF background points, mlp_core.h head_fill4): slot 0 = (x|y), 1 = (z|w), then
+// (sin|cos)(2^k v_c) at slot 2 + 4k + c; embedding columns: 4 raw, then per level [sin x4 | cos x4]
+__global__ void k_pack_h2_head4(_Float16* __restrict__ dst, PackSrc s, int levels, int col_off, int to, int slot_off) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks 0..3, lane, j)
+    if (e >= 4 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * to + i;
+    float w = 0.0f;
+    if (ks < kHeadKSteps) {
+        const int slot = slot_off + 8 * ks + j;
+        int col = -1;
+        if (slot == 0) col = h;
+        else if (slot == 1) col = 2 + h;
+        else if (slot < 2 + 4 * levels) col = 4 + 8 * ((slot - 2) / 4) + 4 * h + ((slot - 2) % 4);
+        if (col >= 0 && row < s.rows_valid) w = s.w[(size_t)(s.row_off + row) * s.ld + col_off + col] * s.scale[s.row_off + row] * s.mul;
+    }
+    store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
+}
+
 }  // namespace iron
 
 using namespace iron;
@@ -250,6 +270,95 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
     const int rc = h2_overflow_check(net);
     if (!net->h2_blob && net->h2_scratch) { (void)hipFree(net->h2_scratch); net->h2_scratch = nullptr; }
     return rc;
+}
+
+// h2 stream of the NeRF background field (models/fields.py:243-327; layers as create_nerf orders them: pts_linears 0..D-1, alpha,
+// feature, views, rgb) for D = 8, skip after layer 4, PE-10 points (42 head slots = two ring slots), PE-4 view dirs (one).  Sequence:
+//   layer 0: per tile [head A][head B];  layers 1..7: per tile [layer 5: head A, head B of the re-concatenated input] hidden;
+//   feature_linear: 8 hidden;  views_linears[0] (128 rows): per tile 0..3 [head = PE(view) columns][hidden = feature columns].
+// Side blocks: biases of layers 0..7 and of feature_linear (9 blocks), rows alpha, rgb 0, rgb 1; the extension block behind them
+// holds the views bias and row rgb 2 (k_nerf_h2 copies it behind the standard LDS map).
+int build_h2_nerf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    const int D = d.n_linear - 4;
+    const int lp = d.multires > 0 ? d.multires : 0, lv = d.multires_view > 0 ? d.multires_view : 0;
+    if (D != 8 || d.skip_layer != 4 || lp != 10 || lv != 4) return IRON_OK;   // fp32 pack only
+    const int in_p = 4 + 8 * lp;
+    std::vector<uint32_t> table;
+    size_t off = 0;
+    auto add = [&](int kind) { table.push_back((uint32_t)off); table.push_back((uint32_t)kind); off += kind ? kSlotBytes : 8192; };
+    for (int to = 0; to < kHidTiles; ++to) { add(0); add(0); }
+    for (int l = 1; l < D; ++l)
+        for (int to = 0; to < kHidTiles; ++to) {
+            if (l == d.skip_layer + 1) { add(0); add(0); }
+            add(1);
+        }
+    for (int to = 0; to < kHidTiles; ++to) add(1);
+    for (int to = 0; to < kHidTiles / 2; ++to) { add(0); add(1); }
+    const uint32_t n_slots = (uint32_t)(table.size() / 2);
+    if (n_slots > 127) return IRON_ERR_UNSUPPORTED;
+    const size_t table_off = (off + 255) & ~(size_t)255;
+    const size_t bias_off = table_off + 1024;
+    const size_t rows_off = bias_off + kLdsBiasBytes;
+    const size_t ext_off = rows_off + kLdsRowsBytes;
+    const size_t total = ext_off + 2048 + 65536;
+    IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
+    IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
+    { const int rc0 = h2_overflow_reset(st); if (rc0 != IRON_OK) return rc0; }
+    char* base = (char*)net->h2_blob;
+    size_t q = 0;
+    auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
+    auto heads4 = [&](const PackSrc& ps, int to) {
+        for (int h = 0; h < 2; ++h, ++q)
+            hipLaunchKernelGGL(k_pack_h2_head4, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, lp, 0, to, h * kHeadSlots);
+    };
+    for (int to = 0; to < kHidTiles; ++to) heads4(make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), to);
+    for (int l = 1; l < D; ++l) {
+        const bool skip_in = (l == d.skip_layer + 1);   // input = [x (in_p) | h (256)]
+        const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f);
+        for (int to = 0; to < kHidTiles; ++to) {
+            if (skip_in) heads4(ps, to);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, skip_in ? in_p : 0, kHidden);
+            ++q;
+        }
+    }
+    {
+        const PackSrc ps = make_pack_src(L[D + 1], scale_base + soff[D + 1], kHidden, 0, 1.0f);
+        for (int to = 0; to < kHidTiles; ++to, ++q)
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
+    }
+    {
+        const PackSrc ps = make_pack_src(L[D + 2], scale_base + soff[D + 2], kHidden / 2, 0, 1.0f);
+        HeadSrcs hv;
+        memset(&hv, 0, sizeof(hv));
+        hv.n = 1; hv.slot_base[0] = 0; hv.levels[0] = lv; hv.col_off[0] = kHidden;
+        for (int to = 0; to < kHidTiles / 2; ++to) {
+            hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hv, to, 0);
+            ++q;
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
+            ++q;
+        }
+    }
+    for (int l = 0; l < D; ++l)
+        hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, kHidden);
+    hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)D * 1024), L[D + 1].bias, 0, kHidden);
+    hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + ext_off), L[D + 2].bias, 0, kHidden / 2);
+    hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)(base + rows_off), make_pack_src(L[D], scale_base + soff[D], 1, 0, 1.0f), 0, 0, kHidden);
+    for (int o = 0; o < 3; ++o)
+        hipLaunchKernelGGL(k_pack_row, dim3(1), dim3(256), 0, st, (float*)(base + (o < 2 ? rows_off + (size_t)(o + 1) * 1024 : ext_off + 1024)),
+                           make_pack_src(L[D + 3], scale_base + soff[D + 3], 3, 0, 1.0f), o, 0, kHidden / 2);
+    IRON_HIP_TRY(hipGetLastError());
+    IRON_HIP_TRY(hipMemcpyAsync(base + table_off, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    IRON_HIP_TRY(hipStreamSynchronize(st));
+    H2StreamDev s;
+    s.base = base; s.table_off = (uint32_t)table_off; s.n_slots = n_slots; s.bias_off = (uint32_t)bias_off;
+    s.rows_off = (uint32_t)rows_off; s.n_bias_layers = (uint32_t)(D + 1);
+    for (int i = 0; i < 4; ++i) s.kind_mask[i] = 0;
+    for (size_t k = 0; k < table.size() / 2; ++k)
+        if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
+    net->h2_trace = s;
+    net->h2_full = s;
+    return h2_overflow_check(net);
 }
 
 }  // namespace iron
