@@ -185,8 +185,14 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad(SdfNetDev net, GradArgs a) 
 // tile: MFMAs (value adds the bias) -> the value wave's epilogue writes sigma'(z) of the tile to a 4 KiB LDS
 // buffer -> barrier -> the tangent waves scale their tile by it.  The feature rows of the last layer are 8 more
 // ring slots that only the value wave multiplies.
-constexpr int kLdsSbuf = kLdsH2Total;               // [16 regs][64 lanes] f32 = 4 KiB
-constexpr int kLdsGradTotal = kLdsH2Total + 4096;
+constexpr int kLdsSbuf = kLdsH2Total;               // 2 x [16 regs][64 lanes] f32 = 2 x 4 KiB (double buffer, tile parity)
+constexpr int kLdsGradTotal = kLdsH2Total + 8192;
+
+#if defined(IRON_GRAD_VARIANT) && (IRON_GRAD_VARIANT & 1)   // timing experiment (garbage results): no activation in the value wave
+#define IRON_GRAD_ACT(Z, H, S) { H = (Z); S = 1.0f; }
+#else
+#define IRON_GRAD_ACT(Z, H, S) softplus100_both<kFastActS>(Z, H, S)
+#endif
 
 __device__ __forceinline__ void lds_publish_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -210,6 +216,7 @@ __device__ __forceinline__ float sdf_value_or_tangent_h2(Ring& ring, char* lds, 
     split_head(head, hd);
     TileFrag dummy_out;
     f32x16 dummy_hf;
+    f32x16 p_hi = zero16(), p_lo = zero16();   // tangent waves: the tile whose sigma' is still on its way
     for (int l = 0; l < m.n_hidden_layers; ++l) {
         const bool last = (l == m.n_hidden_layers - 1);
         const bool with_head = (l == 0) || (l == m.skip_layer);
@@ -232,26 +239,42 @@ __device__ __forceinline__ float sdf_value_or_tangent_h2(Ring& ring, char* lds, 
             step_hidden<kFastActS, 0>(st.rd, bias, st.wr, st.src, st.hidden, wave, lane, TO, false, in, a_hi, a_lo,     \
                                       a_hi, a_lo, dummy_out, dummy_hf);                                                 \
         }                                                                                                               \
-        f32x16 zt = h2_combine(a_hi, a_lo);                                                                             \
         if (is_value) {                                                                                                 \
+            /* value wave: activation of tile TO now; sigma'(z) goes to sbuf[TO & 1] for the tangent waves, which pick */ \
+            /* it up one ring step later (behind that step's barrier)                                                  */ \
+            f32x16 zt = h2_combine(a_hi, a_lo);                                                                         \
             const f32x16 bt = lds_half_tile(bias, TO, half);                                                            \
+            float* sb = sbuf + ((TO) & 1) * (16 * 64);                                                                  \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
                 float hv, sv;                                                                                           \
-                softplus100_both<kFastActS>(zt[r] + bt[r], hv, sv);                                                     \
+                IRON_GRAD_ACT(zt[r] + bt[r], hv, sv);                                                                   \
                 zt[r] = hv;                                                                                             \
-                sbuf[r * 64 + lane] = sv;                                                                               \
+                sb[r * 64 + lane] = sv;                                                                                 \
             }                                                                                                           \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+            if (last) out[TO] = __builtin_bit_cast(TileFrag, zt);                                                       \
+            else split_tile(zt, out[TO]);                                                                               \
+        } else {                                                                                                        \
+            /* tangent waves: finish tile TO - 1 (its sigma' was published during the previous step), keep TO pending  */ \
+            if ((TO) > 0) IRON_GTANGENT_FINISH((TO) - 1)                                                                \
+            p_hi = a_hi;                                                                                                \
+            p_lo = a_lo;                                                                                                \
         }                                                                                                               \
-        lds_publish_barrier();                                                                                          \
-        if (!is_value) {                                                                                                \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) zt[r] *= sbuf[r * 64 + lane];                                \
-        }                                                                                                               \
-        /* the last layer's f32 tile travels in the SAME 16 registers its split fragments would use (hf materialises  */  \
-        /* after the loop): a separate hf[8] live through the runtime layer loop costs 128 VGPRs -> 100+ spilled        */  \
-        if (last) out[TO] = __builtin_bit_cast(TileFrag, zt);                                                           \
-        else split_tile(zt, out[TO]);                                                                                   \
+    }
+/* the last hidden layer's f32 tile travels in the SAME 16 registers its split fragments would use (hf materialises after the */
+/* loop): a separate hf[8] live through the runtime layer loop costs 128 VGPRs -> 100+ spilled                                   */
+#define IRON_GTANGENT_FINISH(T)                                                                                         \
+    {                                                                                                                   \
+        f32x16 zt = h2_combine(p_hi, p_lo);                                                                             \
+        const float* sb = sbuf + ((T) & 1) * (16 * 64);                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) zt[r] *= sb[r * 64 + lane];                                      \
+        if (last) out[T] = __builtin_bit_cast(TileFrag, zt);                                                            \
+        else split_tile(zt, out[T]);                                                                                    \
     }
         IRON_GTILE(0) IRON_GTILE(1) IRON_GTILE(2) IRON_GTILE(3) IRON_GTILE(4) IRON_GTILE(5) IRON_GTILE(6) IRON_GTILE(7)
+        lds_publish_barrier();   // sigma' of tile 7 is out; (also orders this layer's last sbuf reads before the next layer's writes)
+        if (!is_value) IRON_GTANGENT_FINISH(7)
+#undef IRON_GTANGENT_FINISH
 #undef IRON_GTILE
     }
     f32x16 hf[kHidTiles];  // last hidden layer in f32 (value: h7, tangent: d h7)
