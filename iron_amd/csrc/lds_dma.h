@@ -20,6 +20,15 @@ __device__ __forceinline__ void lds_dma16(const char* src, uint32_t lds_base) {
 __device__ __forceinline__ void lds_dma4(const char* src, uint32_t lds_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_base) : "memory");
 }
+// The same with the address split as the ISA's saddr form wants it: a wave-uniform 64-bit base in SGPRs + one 32-bit per-lane offset
+// (lane * 16 or lane * 4, a constant VGPR).  A ring refill then costs the vector port nothing per piece: the base moves by scalar adds
+// (the per-lane 64-bit pointer form needs one v_lshl_add_u64 per piece, 17 per ring step in k_sdf_values_h2).
+__device__ __forceinline__ void lds_dma16_s(const char* base_uniform, uint32_t lane_off, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base_uniform), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_s(const char* base_uniform, uint32_t lane_off, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_off), "s"(base_uniform), "s"(lds_base) : "memory");
+}
 // wave-uniform LDS byte address of a (generic) pointer into __shared__ memory: the low half of the flat address IS the LDS offset
 // (aperture base in the high half); an addrspacecast would add a null check, which hipcc 7.2 mis-selects in some kernels
 // ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base")

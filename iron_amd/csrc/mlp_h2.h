@@ -238,33 +238,55 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
     return;
 #endif
     const int lane = threadIdx.x & 63;
-    const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
 #if IRON_H2_ASM_DMA
-    const uint32_t wr_lds = lds_addr_of(wr);
-#endif
+    // uniform base in SGPRs + a constant per-lane offset (lds_dma.h): no vector instruction per piece
+    // running scalar pointers, opaque to the optimiser: hoisted out of the unrolled evaluation as loop invariants, the 16 piece
+    // offsets (wave + 4 i) * {1024, 256} overflow the SGPR file and come back per step as v_readlane of a spill register
+    // (readfirstlane: in the tracer kernels the ring state travels through code the uniformity analysis gives up on)
+    int w = __builtin_amdgcn_readfirstlane(wave);
+    asm volatile("" : "+s"(w));
+    const unsigned long long gp = (unsigned long long)(src.gbase + src.off);
+    const char* gstep = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gp >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gp));
+    if (hidden) {
+        const uint32_t lo = (uint32_t)lane * 16u;
+        const char* g = gstep + w * 1024;
+        uint32_t l = lds_addr_of(wr) + w * 1024;
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            lds_dma16_s(g, lo, l);
+            g += 4096; l += 4096;
+            asm volatile("" : "+s"(g), "+s"(l));
+        }
+    } else {
+        const uint32_t lo = (uint32_t)lane * 4u;
+        const char* g = gstep + w * 256;
+        uint32_t l = lds_addr_of(wr) + w * 256;
+#pragma unroll
+        for (int i = 0; i < kLoadsPerSlot; ++i) {
+            lds_dma4_s(g, lo, l);
+            g += 1024; l += 1024;
+            asm volatile("" : "+s"(g), "+s"(l));
+        }
+    }
+#else
+    const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
     if (hidden) {
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
-#if IRON_H2_ASM_DMA
-            lds_dma16(gsrc + f * 1024, wr_lds + f * 1024);
-#else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
                                              (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
-#endif
         }
     } else {
 #pragma unroll
         for (int i = 0; i < kLoadsPerSlot; ++i) {
             const int f = wave + 4 * i;
-#if IRON_H2_ASM_DMA
-            lds_dma4(gsrc + f * 256, wr_lds + f * 256);
-#else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
                                              (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
-#endif
         }
     }
+#endif
 }
 
 __device__ __forceinline__ void ring_start(Ring& r, const H2StreamDev& s, char* lds_base, int wave, int lane) {
