@@ -101,7 +101,9 @@ int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sd
                      float* grad, void* stream);
 
 /* RenderingNetwork.forward (models/fields.py:203-239).  view_dirs may be NULL for modes that do
- * not read it.  out [n,d_out]. */
+ * not read it.  out [n,d_out].
+ * A net with a skip connection (skip_layer >= 1: the stage-1 colour net) parks the skip layer's partial sums in a scratch buffer
+ * owned by the handle: calls on ONE such handle must be ordered on one stream (different handles are independent). */
 int iron_render_forward(const iron_net_t* net, const float* points, const float* normals,
                         const float* view_dirs, const float* features, int64_t n, float* out, void* stream);
 

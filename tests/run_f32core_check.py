@@ -36,4 +36,17 @@ flips = int((conv != g["convergent_mask"]).sum())
 both = conv & g["convergent_mask"]
 r_col = rel_l2(res["color"].cpu().numpy()[both], g["color"][both])
 assert flips == 0 and r_col <= 1e-4, (flips, r_col)
+# stage-1 networks on the exact core (k_material<10, 4, ..., skip>, k_nerf): the h2 kernels are the default elsewhere
+from iron_amd.fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork  # noqa: E402
+
+torch.manual_seed(0)
+SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0, geometric_init=True, weight_norm=True)
+cnet = RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=8, skip_in=[4], weight_norm=True,
+                        multires=10, multires_view=4, squeeze_out=True).cuda()
+nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True).cuda()
+g = golden("g13_neus.npz")
+co = cnet(t(g["color_pts"]).cuda(), t(g["color_nrm"]).cuda(), t(g["color_view"]).cuda(), t(g["color_feat"]).cuda())
+na, nc = nerf(t(g["nerf_pts"]).cuda(), t(g["nerf_views"]).cuda())
+r_c1, r_na, r_nc = rel_l2(co.cpu().numpy(), g["color_out"]), rel_l2(na.cpu().numpy(), g["nerf_alpha"]), rel_l2(nc.cpu().numpy(), g["nerf_rgb"])
+assert r_c1 <= 1e-5 and r_na <= 1e-5 and r_nc <= 1e-5, (r_c1, r_na, r_nc)
 print("F32CORE_CHECK OK sdf %.2e grad %.2e colour %.2e flips %d" % (r_sdf, r_grad, r_col, flips))

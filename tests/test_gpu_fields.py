@@ -106,8 +106,9 @@ def test_fp16_overflowing_weight_selects_the_fp32_core():
 
 def test_stage1_colour_network_with_skip():
     """RenderingNetwork(n_layers=8, skip_in=[4], multires=10, multires_view=4) -- the stage-1 colour net of
-    confs/womask_iron.conf: 48 head slots (PE-10 points, PE-4 views, normals) and a skip connection at hidden layer 4;
-    runs on the exact-fp32 core (no h2 stream is built for it).  Golden: G13 (the real reference)."""
+    confs/womask_iron.conf: 48 head slots (PE-10 points, PE-4 views, normals: two head ring slots) and a skip connection at hidden
+    layer 4, on the h2 core (k_material_h2_skip; tests/run_f32core_check.py covers the exact-fp32 kernel).  Golden: G13 (the real
+    reference).  Ragged batches around the 32-point wave tile and the 128-point workgroup must reproduce the full batch."""
     from iron_amd.fields import RenderingNetwork, SDFNetwork
     torch.manual_seed(0)
     SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0, geometric_init=True,
@@ -122,10 +123,11 @@ def test_stage1_colour_network_with_skip():
     err = np.abs(out.cpu().numpy() - g["color_out"]).max()
     print("stage-1 colour net: rel-L2 %.2e  max|d| %.2e" % (rel_l2(out.cpu().numpy(), g["color_out"]), err))
     assert rel_l2(out.cpu().numpy(), g["color_out"]) <= 1e-5
-    for n in (1, 33):
+    n_all = out.shape[0]
+    for n in (1, 33, 127, 129, min(513, n_all)):
         with torch.no_grad():
             o2 = net(t(g["color_pts"]).cuda()[:n], t(g["color_nrm"]).cuda()[:n], t(g["color_view"]).cuda()[:n], t(g["color_feat"]).cuda()[:n])
-        np.testing.assert_allclose(o2.cpu().numpy(), out[:n].cpu().numpy(), rtol=0, atol=1e-6)
+        assert torch.equal(o2, out[:n]), n   # every point is computed independently of its neighbours
 
 
 def test_nerf_background_field():
@@ -151,6 +153,11 @@ def test_nerf_background_field():
     ra, rc = rel_l2(alpha.cpu().numpy(), g["nerf_alpha"]), rel_l2(rgb.cpu().numpy(), g["nerf_rgb"])
     print("NeRF: alpha rel-L2 %.2e  rgb rel-L2 %.2e" % (ra, rc))
     assert ra <= 1e-5 and rc <= 1e-5
+    pts, views = t(g["nerf_pts"]).cuda(), t(g["nerf_views"]).cuda()
+    for n in (1, 33, 127, 129, min(513, alpha.shape[0])):   # ragged batches (k_nerf_h2: 4 waves x 32 points per workgroup)
+        with torch.no_grad():
+            a2, c2 = nerf(pts[:n].contiguous(), views[:n].contiguous())
+        assert torch.equal(a2, alpha[:n]) and torch.equal(c2, rgb[:n]), n
 
 
 def test_material_predictor_and_bulk_query():
