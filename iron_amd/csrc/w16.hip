@@ -70,9 +70,12 @@ __global__ void k_pack_w16_vec(float* __restrict__ dst, const float* __restrict_
     if (e < 256) dst[e] = e < n_valid ? src[e] * (scale ? scale[0] : 1.0f) : 0.0f;
 }
 
+bool use_w16_core();
+
 int build_w16_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st) {
     const iron_net_desc& d = net->desc;
     const int nl = d.n_linear, skip = d.skip_layer, pe = pe_width(d.multires);
+    if (!use_w16_core()) return IRON_OK;                                             // the prototype core packs only when it is selected
     if (d.d_hidden != kHidden || nl != 9 || skip != 4 || pe > 64) return IRON_OK;   // the 8 x 256 skip-4 SDF network only
     std::vector<uint32_t> table;
     size_t off = 0;
