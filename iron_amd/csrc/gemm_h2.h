@@ -303,6 +303,34 @@ __global__ void k_gemm_pack_b(PackBArgs p) {
     *reinterpret_cast<g_u32x4*>(dst + 1024) = lo;
 }
 
+// Fused epilogues of the row kernel (train.hip: the layer-wise backward of the SDF and material networks).  The activation and the
+// activation-gradient passes over a layer's [R, 256] arrays are HBM-bound kernels of their own otherwise: one more read of what the
+// GEMM has just written, one more write.
+//   kEpiPlain     C = A B (+ beta C)
+//   kEpiSdfAct    forward recompute of an SDF layer: z = A B + bias -> Z (kept for the reverse pass), next = (softplus_100(z),
+//                 sigma'(z) zdot) * sc, written straight into the next layer's input
+//   kEpiSdfBack   reverse of it: the product is dL/d(next layer input); with Z of THIS layer: dZ = (s1 abar + s2 zdot adotbar,
+//                 s1 adotbar), the bias gradient (column sums of the value rows) and |dZ|_max on the way
+//   kEpiReluAct / kEpiReluBack   the same two for a relu layer of a material network (no tangent rows)
+// PAIRED rows (SDF net under a gradient loss): the rows are [values of m points | tangents of the same m points]; a block then
+// takes 32 points and puts their value rows in row tile 0 and their tangent rows in row tile 1, so that z and zdot of one
+// (point, feature) sit in the same lane and register index of the two accumulator tiles.
+enum { kEpiPlain = 0, kEpiSdfAct = 1, kEpiSdfBack = 2, kEpiReluAct = 3, kEpiReluBack = 4 };
+
+struct RowsEpi {
+    int paired;            // rows are [m_pts values | m_pts tangents]
+    int m_pts;
+    int n_act;             // columns [0, n_act) carry the activation (the rest of the product is ignored / plain)
+    float sc;
+    const float* bias;     // Act: [n_act]
+    float* Z;              // Act: out [R, ldz];  Back: in
+    int ldz;
+    float* out;            // Act: next layer's input [R, ld_out];  Back: dZ [R, ld_out]
+    int ld_out;
+    float* db;             // Back: [n_act] bias gradient (atomicAdd)
+    float* amax_out;       // Back: |dZ|_max (atomicMax on the bit pattern), or null
+};
+
 struct RowsArgs {
     const float* A;        // [R, K], row stride lda
     const char* Bp;        // packed fragments (k_gemm_pack_b)
@@ -310,10 +338,42 @@ struct RowsArgs {
     int lda, ldc, R, N, K, k_steps, n_tiles;
     const float* a_absmax; // device scalar or null
     float beta;
+    RowsEpi e;
 };
 
+// F.softplus(beta = 100, threshold = 20) with its first two derivatives (models/fields.py:80)
+__device__ __forceinline__ void softplus100(float z, float* a, float* s1, float* s2) {
+    const float bz = 100.0f * z;
+    if (bz > 20.0f) { *a = z; *s1 = 1.0f; *s2 = 0.0f; return; }
+    const float e = expf(bz);
+    *a = log1pf(e) / 100.0f;
+    *s1 = e / (e + 1.0f);
+    *s2 = 100.0f * (*s1) * (1.0f - *s1);
+}
+
+// The same on the hardware exp2 / log2 / rcp (1 ulp each), for the fused epilogues: there the activation runs at the row kernel's two
+// waves per SIMD, and expf / log1pf (~60 instructions per element) would cost more than the tile's MFMAs.  u = exp(-|100 z|) never
+// overflows; above the reference's threshold (100 z > 20) u < 2^-24, so 1 + u == 1 and (a, s1, s2) = (z, 1, 0) exactly as there.
+__device__ __forceinline__ void softplus100_fast(float z, float* a, float* s1, float* s2) {
+    const float u = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);
+    const float w = 1.0f + u;
+    const float r = __builtin_amdgcn_rcpf(w);
+    *a = fmaf(__builtin_amdgcn_logf(w), 0.0069314718055994531f, fmaxf(z, 0.0f));
+    const float sg = (z >= 0.0f ? 1.0f : u) * r;
+    *s1 = sg;
+    *s2 = 100.0f * sg * ((z >= 0.0f ? u : 1.0f) * r);   // 1 - sigmoid without cancellation
+}
+
+// wave maximum -> one atomicMax per wave on the float's bit pattern (values >= 0).  Called by EVERY lane of the wave.
+__device__ __forceinline__ void publish_absmax(float m, float* out) {
+    if (!out) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+
 // NTW = column tiles (of 32) per wave: the workgroup covers 4 * NTW * 32 columns
-template <int NTW>
+template <int NTW, int EPI = kEpiPlain>
 __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs g) {   // NTW <= 2: <= 256 registers, two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char g_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,9 +382,15 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
     const bool vec_ok = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
     const int k_chunks = g.k_steps * 2;                    // 8-wide chunks per row
     const int n_seg = kRowsBM * k_chunks;                  // segments of the 64-row block
-    const int n_blocks = (g.R + kRowsBM - 1) / kRowsBM;
+    const bool paired = EPI != kEpiPlain && g.e.paired != 0;
+    const int n_blocks = paired ? (g.e.m_pts + 31) / 32 : (g.R + kRowsBM - 1) / kRowsBM;
+    // global row of block row r (0..63), or -1
+    auto row_of = [&](int blk, int r) -> int {
+        if (!paired) { const int gr = blk * kRowsBM + r; return gr < g.R ? gr : -1; }
+        const int p = blk * 32 + (r & 31);
+        return p < g.e.m_pts ? (r < 32 ? p : g.e.m_pts + p) : -1;
+    };
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int r0 = blk * kRowsBM;
         // ---- the block's rows -> split -> LDS fragment image: four segments per thread at a time, all their loads issued before
         // the first split (one HBM latency per batch instead of one per segment)
         for (int s0 = tid; s0 < n_seg; s0 += 4 * 256) {
@@ -333,14 +399,14 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
             for (int u = 0; u < 4; ++u) {
                 const int s = s0 + 256 * u;
                 const int r = s / k_chunks, c = s - r * k_chunks;   // consecutive threads: consecutive chunks of one row (coalesced)
-                const int gr = r0 + r, k0 = c * 8;
-                const float* p = g.A + (size_t)gr * g.lda + k0;
-                if (s < n_seg && gr < g.R && vec_ok && k0 + 8 <= g.K) {
+                const int gr = s < n_seg ? row_of(blk, r) : -1, k0 = c * 8;
+                const float* p = g.A + (size_t)(gr < 0 ? 0 : gr) * g.lda + k0;
+                if (gr >= 0 && vec_ok && k0 + 8 <= g.K) {
                     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
                     v[u][0] = a.x; v[u][1] = a.y; v[u][2] = a.z; v[u][3] = a.w; v[u][4] = b.x; v[u][5] = b.y; v[u][6] = b.z; v[u][7] = b.w;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[u][i] = (s < n_seg && gr < g.R && k0 + i < g.K) ? p[i] : 0.0f;
+                    for (int i = 0; i < 8; ++i) v[u][i] = (gr >= 0 && k0 + i < g.K) ? p[i] : 0.0f;
                 }
             }
 #pragma unroll
@@ -422,35 +488,101 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
             }
         }
         // ---- epilogue
+        if constexpr (EPI == kEpiPlain) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int n = (nt0 + j) * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = blk * kRowsBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (m < g.R && n < g.N) {
+                            const float v = fmaf(acc_lo[i][j][r], kGemmLoInv, acc_hi[i][j][r]) * unscale;
+                            float* dst = g.C + (size_t)m * g.ldc + n;
+                            *dst = g.beta != 0.0f ? fmaf(g.beta, *dst, v) : v;
+                        }
+                    }
+                }
+        } else {
+            const RowsEpi& e = g.e;
+            float mx = 0.0f;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n = (nt0 + j) * 32 + (lane & 31);
+                const bool col_ok = n < e.n_act;
+                const float bias = (col_ok && (EPI == kEpiSdfAct || EPI == kEpiReluAct)) ? e.bias[n] : 0.0f;
+                float colsum = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = r0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < g.R && n < g.N) {
-                        const float v = fmaf(acc_lo[i][j][r], kGemmLoInv, acc_hi[i][j][r]) * unscale;
-                        float* dst = g.C + (size_t)m * g.ldc + n;
-                        *dst = g.beta != 0.0f ? fmaf(g.beta, *dst, v) : v;
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v0 = fmaf(acc_lo[0][j][r], kGemmLoInv, acc_hi[0][j][r]) * unscale;
+                    const float v1 = fmaf(acc_lo[1][j][r], kGemmLoInv, acc_hi[1][j][r]) * unscale;
+                    const int m0 = row_of(blk, rr), m1 = row_of(blk, 32 + rr);
+                    if (!col_ok) continue;
+                    if constexpr (EPI == kEpiSdfAct) {
+                        if (paired) {   // (z, zdot) of one point
+                            if (m0 >= 0) {
+                                const float z = v0 + bias;
+                                float a, s1, s2;
+                                softplus100_fast(z, &a, &s1, &s2);
+                                e.Z[(size_t)m0 * e.ldz + n] = z;
+                                e.Z[(size_t)m1 * e.ldz + n] = v1;
+                                e.out[(size_t)m0 * e.ld_out + n] = a * e.sc;
+                                e.out[(size_t)m1 * e.ld_out + n] = s1 * v1 * e.sc;
+                            }
+                        } else {
+                            float a, s1, s2;
+                            if (m0 >= 0) { const float z = v0 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = a * e.sc; }
+                            if (m1 >= 0) { const float z = v1 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = a * e.sc; }
+                        }
+                    } else if constexpr (EPI == kEpiSdfBack) {
+                        if (paired) {
+                            if (m0 >= 0) {
+                                float a, s1, s2;
+                                softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2);
+                                const float abar = v0 * e.sc, adotbar = v1 * e.sc;
+                                const float zd = e.Z[(size_t)m1 * e.ldz + n];
+                                const float zbar = s1 * abar + s2 * zd * adotbar, tbar = s1 * adotbar;
+                                e.out[(size_t)m0 * e.ld_out + n] = zbar;
+                                e.out[(size_t)m1 * e.ld_out + n] = tbar;
+                                colsum += zbar;
+                                mx = fmaxf(mx, fmaxf(fabsf(zbar), fabsf(tbar)));
+                            }
+                        } else {
+                            float a, s1, s2;
+                            if (m0 >= 0) { softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v0 * e.sc); e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                            if (m1 >= 0) { softplus100_fast(e.Z[(size_t)m1 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v1 * e.sc); e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                        }
+                    } else if constexpr (EPI == kEpiReluAct) {
+                        if (m0 >= 0) { const float z = v0 + bias; e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
+                        if (m1 >= 0) { const float z = v1 + bias; e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
+                    } else {   // kEpiReluBack
+                        if (m0 >= 0) { const float zb = e.Z[(size_t)m0 * e.ldz + n] > 0.0f ? v0 * e.sc : 0.0f; e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                        if (m1 >= 0) { const float zb = e.Z[(size_t)m1 * e.ldz + n] > 0.0f ? v1 * e.sc : 0.0f; e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
                     }
                 }
+                if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) {
+                    colsum += __shfl_xor(colsum, 32, 64);   // the two lane halves hold the other rows of the same column
+                    if (lane < 32 && col_ok && e.db) atomicAdd(&e.db[n], colsum);
+                }
             }
+            if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) publish_absmax(mx, e.amax_out);
+        }
         __syncthreads();   // the image is rewritten by the next block
     }
 }
 
-template <int NTW>
+template <int NTW, int EPI = kEpiPlain>
 static inline hipError_t gemm_rows_launch(const RowsArgs& g, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_gemm_rows<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, kRowsLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_gemm_rows<NTW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kRowsLdsBytes);
         attr = true;
     }
-    const int n_blocks = (g.R + kRowsBM - 1) / kRowsBM;
+    const int n_blocks = (EPI != kEpiPlain && g.e.paired) ? (g.e.m_pts + 31) / 32 : (g.R + kRowsBM - 1) / kRowsBM;
     const int lds = 2 * g.k_steps * 2 * 1024;
-    hipLaunchKernelGGL((k_gemm_rows<NTW>), dim3(n_blocks < 1024 ? n_blocks : 1024), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((k_gemm_rows<NTW, EPI>), dim3(n_blocks < 1024 ? n_blocks : 1024), dim3(256), lds, st, g);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "../../include/iron_train.h"
@@ -37,13 +38,22 @@ struct GemmCtx {
     size_t pack_floats;
 };
 
+// IRON_TRAIN_FUSE=0 keeps the activation passes as kernels of their own (A/B switch; the default fuses them into the row GEMMs)
+static bool fused_epilogues() {
+    static const bool v = [] { const char* e = getenv("IRON_TRAIN_FUSE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 // row-major C[m,n] = op(A) op(B) + beta C;  A is [m,k] (or [k,m] when ta), B is [k,n] (or [n,k] when tb).
 // Three shapes occur: Z = X W^T (ta = 0, tb = 1: forward recompute, operands as they are), dX = dZ W (ta = 0, tb = 0) and the
 // small-K leftovers of dW = dZ^T X (ta = 1, tb = 0): in the last two A is a gradient and carries a power-of-two scale from its
 // absolute maximum (gemm_h2.h).
 // `amax`: device scalar already holding |A|_max (written by the kernel that produced A: publish_absmax), or null -> one pass over A.
+// `epi` (with `epi_mode` != kEpiPlain): the activation / activation-gradient pass fused into the row kernel's epilogue (gemm_h2.h);
+// *fused tells the caller whether it was (the shapes the row kernel does not take run the plain product into C).
 static int gemm_rm(const GemmCtx& h, bool ta, bool tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float beta,
-                   float* C, int ldc, const float* amax = nullptr) {
+                   float* C, int ldc, const float* amax = nullptr, int epi_mode = kEpiPlain, const RowsEpi* epi = nullptr, bool* fused = nullptr) {
+    if (fused) *fused = false;
     if (m == 0 || n == 0) return IRON_OK;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.beta = beta;
@@ -67,7 +77,18 @@ static int gemm_rm(const GemmCtx& h, bool ta, bool tb, int m, int n, int k, cons
         RowsArgs r;
         r.A = A; r.Bp = (const char*)h.pack; r.C = C; r.lda = lda; r.ldc = ldc; r.R = m; r.N = n; r.K = k; r.k_steps = k_steps; r.n_tiles = n_tiles;
         r.a_absmax = g.a_absmax; r.beta = beta;
-        const hipError_t er = n_tiles <= 4 ? gemm_rows_launch<1>(r, h.st) : (n_tiles <= 8 ? gemm_rows_launch<2>(r, h.st) : gemm_rows_launch<3>(r, h.st));
+        memset(&r.e, 0, sizeof(r.e));
+        hipError_t er;
+        if (epi_mode != kEpiPlain && epi && n_tiles > 4 && n_tiles <= 8 && fused_epilogues()) {   // the 256- and 217-wide layers
+            r.e = *epi;
+            if (epi_mode == kEpiSdfAct) er = gemm_rows_launch<2, kEpiSdfAct>(r, h.st);
+            else if (epi_mode == kEpiSdfBack) er = gemm_rows_launch<2, kEpiSdfBack>(r, h.st);
+            else if (epi_mode == kEpiReluAct) er = gemm_rows_launch<2, kEpiReluAct>(r, h.st);
+            else er = gemm_rows_launch<2, kEpiReluBack>(r, h.st);
+            if (fused) *fused = true;
+        } else {
+            er = n_tiles <= 4 ? gemm_rows_launch<1>(r, h.st) : (n_tiles <= 8 ? gemm_rows_launch<2>(r, h.st) : gemm_rows_launch<3>(r, h.st));
+        }
         TR_HIP(er);
         return IRON_OK;
     }
@@ -210,15 +231,6 @@ __global__ void k_sdf_in(const float* __restrict__ x, const float* __restrict__ 
     }
 }
 
-__device__ __forceinline__ void softplus100(float z, float* a, float* s1, float* s2) {
-    const float bz = 100.0f * z;
-    if (bz > 20.0f) { *a = z; *s1 = 1.0f; *s2 = 0.0f; return; }  // F.softplus threshold
-    const float e = expf(bz);
-    *a = log1pf(e) / 100.0f;
-    *s1 = e / (e + 1.0f);
-    *s2 = 100.0f * (*s1) * (1.0f - *s1);
-}
-
 // Z [R, out] (R = m or 2m): add bias to the value rows in place; next[:, 0:out) = (softplus(z), sigma'(z) zdot) * sc
 __global__ void k_sdf_act(float* __restrict__ Z, const float* __restrict__ bias, int m, int out, int tangent, float sc, float* __restrict__ next,
                           int ld_next) {
@@ -263,12 +275,6 @@ static inline dim3 strip_grid(int m, int out) { return dim3((out + 255) / 256, (
 // |dZ|_max as a by-product of the kernels that WRITE a layer's dZ (the split-fp16 GEMMs scale their gradient operand by it,
 // gemm_h2.h): wave maximum, one atomicMax per wave.  Called by EVERY lane of the wave (STRIP_PROLOGUE_LIVE keeps the lanes of a
 // partial last block alive with `live` = false and m = 0).
-__device__ __forceinline__ void publish_absmax(float m, float* out) {
-    if (!out) return;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
-}
 #define STRIP_PROLOGUE_LIVE(m, out)                             \
     const int c = blockIdx.x * blockDim.x + threadIdx.x;        \
     const bool live = c < (out);                                \
@@ -380,28 +386,52 @@ static int sdf_backward(const iron_sdf_train_desc* d, const float* x, int64_t n,
         hipLaunchKernelGGL(k_sdf_in, grid1((int64_t)m * D0), dim3(256), 0, st, x + 3 * p0, d_grad ? d_grad + 3 * p0 : nullptr, m, d->multires, P.IN[0]);
         for (int l = 0; l + 1 < L; ++l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim, in_next = ly[l + 1].in_dim;
-            TR_TRY(gemm_rm(h, false, true, R, out, in, P.IN[l], in, P.W[l], in, 0.0f, P.Z[l], out));
             const bool to_skip = (l + 1 == d->skip_layer);
-            hipLaunchKernelGGL(k_sdf_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, tangent, to_skip ? rs2 : 1.0f,
-                               P.IN[l + 1], in_next);
+            RowsEpi ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.paired = tangent; ea.m_pts = m; ea.n_act = out; ea.sc = to_skip ? rs2 : 1.0f; ea.bias = ly[l].bias;
+            ea.Z = P.Z[l]; ea.ldz = out; ea.out = P.IN[l + 1]; ea.ld_out = in_next;
+            bool fused = false;
+            TR_TRY(gemm_rm(h, false, true, R, out, in, P.IN[l], in, P.W[l], in, 0.0f, P.Z[l], out, nullptr, kEpiSdfAct, &ea, &fused));
+            if (!fused)
+                hipLaunchKernelGGL(k_sdf_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, tangent, to_skip ? rs2 : 1.0f,
+                                   P.IN[l + 1], in_next);
             if (to_skip)
                 hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)R * D0), dim3(256), 0, st, P.IN[0], D0, R, D0, rs2, P.IN[l + 1], in_next, out);
         }
         // reverse
         const int out_last = ly[L - 1].out_dim;
-        float* dz_max = h.scratch + 1;  // |dZ|_max of the layer in flight, written by the kernel that writes dZ
-        TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
+        // |dZ|_max of a layer is written by the kernel that writes its dZ; two scalars in turn, because the fused row GEMM reads the
+        // maximum of its operand (this layer's dZ) while its epilogue publishes the next one's.  dZ itself alternates between P.dZ and
+        // P.dX for the same reason (a block's output rows are other blocks' input rows when the widths differ).
+        float* dz_max_cur = h.scratch + 1;
+        float* dz_max_nxt = h.scratch + 2;
+        float* dz_cur = P.dZ;
+        float* dz_nxt = P.dX;
+        TR_HIP(hipMemsetAsync(dz_max_cur, 0, sizeof(float), st));
         hipLaunchKernelGGL(k_sdf_seed, strip_grid(m, out_last), dim3(256), 0, st, d_sdf ? d_sdf + p0 : nullptr,
-                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, P.dZ, P.db[L - 1], dz_max);
+                           d_feat ? d_feat + (size_t)p0 * (out_last - 1) : nullptr, m, out_last, tangent, dz_cur, P.db[L - 1], dz_max_cur);
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_dw(h, st, out, in, R, P.dZ, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, dz_max));
+            TR_TRY(gemm_dw(h, st, out, in, R, dz_cur, P.IN[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, dz_max_cur));
             if (l == 0) break;
-            TR_TRY(gemm_rm(h, false, false, R, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in, dz_max));
             const int outp = ly[l - 1].out_dim;
-            TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
-            hipLaunchKernelGGL(k_sdf_act_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, tangent,
-                               l == d->skip_layer ? rs2 : 1.0f, P.dZ, P.db[l - 1], dz_max);
+            const float sc = l == d->skip_layer ? rs2 : 1.0f;
+            TR_HIP(hipMemsetAsync(dz_max_nxt, 0, sizeof(float), st));
+            RowsEpi eb;
+            memset(&eb, 0, sizeof(eb));
+            eb.paired = tangent; eb.m_pts = m; eb.n_act = outp; eb.sc = sc; eb.Z = P.Z[l - 1]; eb.ldz = outp;
+            eb.out = dz_nxt; eb.ld_out = outp; eb.db = P.db[l - 1]; eb.amax_out = dz_max_nxt;
+            bool fused = false;
+            // unfused: the product goes to dz_nxt (as dX, row length `in`), k_sdf_act_back turns it into dZ of layer l - 1 in dz_cur
+            TR_TRY(gemm_rm(h, false, false, R, in, out, dz_cur, out, P.W[l], in, 0.0f, dz_nxt, in, dz_max_cur, kEpiSdfBack, &eb, &fused));
+            if (fused) {
+                float* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
+            } else {
+                hipLaunchKernelGGL(k_sdf_act_back, strip_grid(m, outp), dim3(256), 0, st, dz_nxt, in, P.Z[l - 1], m, outp, tangent, sc, dz_cur,
+                                   P.db[l - 1], dz_max_nxt);
+            }
+            float* tm = dz_max_cur; dz_max_cur = dz_max_nxt; dz_max_nxt = tm;
         }
     }
     for (int l = 0; l < L; ++l) {
@@ -576,11 +606,20 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
                            feat ? feat + (size_t)p0 * I.nf : nullptr, m, P.X[0]);
         for (int l = 0; l < L; ++l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            TR_TRY(gemm_rm(h, false, true, m, out, in, P.X[l], in, P.W[l], in, 0.0f, P.Z[l], out));
-            if (l + 1 == L) break;
+            if (l + 1 == L) {
+                TR_TRY(gemm_rm(h, false, true, m, out, in, P.X[l], in, P.W[l], in, 0.0f, P.Z[l], out));
+                break;
+            }
             const bool to_skip = (l + 1 == d->skip_layer);
             const int in_next = ly[l + 1].in_dim;
-            hipLaunchKernelGGL(k_relu_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, to_skip ? rs2 : 1.0f, P.X[l + 1], in_next);
+            RowsEpi ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.m_pts = m; ea.n_act = out; ea.sc = to_skip ? rs2 : 1.0f; ea.bias = ly[l].bias; ea.Z = P.Z[l]; ea.ldz = out;
+            ea.out = P.X[l + 1]; ea.ld_out = in_next;
+            bool fused = false;
+            TR_TRY(gemm_rm(h, false, true, m, out, in, P.X[l], in, P.W[l], in, 0.0f, P.Z[l], out, nullptr, kEpiReluAct, &ea, &fused));
+            if (!fused)
+                hipLaunchKernelGGL(k_relu_act, grid1((int64_t)m * out), dim3(256), 0, st, P.Z[l], ly[l].bias, m, out, to_skip ? rs2 : 1.0f, P.X[l + 1], in_next);
             if (to_skip)
                 hipLaunchKernelGGL(k_copy_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.X[0], I.D0, m, I.D0, rs2, P.X[l + 1], in_next, out);
         }
@@ -588,21 +627,40 @@ static int render_backward(const iron_render_train_desc* d, const float* pts, co
         hipLaunchKernelGGL(k_render_out_back, strip_grid(m, out_last), dim3(256), 0, st, P.Z[L - 1], ly[L - 1].bias, d_out + (size_t)p0 * out_last, m,
                            out_last, d->output_bias, d->output_scale, d->squeeze_out, d->squeeze_out_scale, P.dZ, P.db[L - 1]);
         TR_HIP(hipMemsetAsync(P.dIN0, 0, sizeof(float) * (size_t)m * I.D0, st));
-        float* dz_max = h.scratch + 1;  // |dZ|_max of the layer in flight, written by k_relu_back (the 3-wide seed of the last layer: one tiny pass)
+        // |dZ|_max of the layer in flight, written by the kernel that writes its dZ (the 3-wide seed of the last layer: one tiny pass);
+        // scalars and dZ buffers in turn as in sdf_backward
+        float* dz_max_cur = h.scratch + 1;
+        float* dz_max_nxt = h.scratch + 2;
+        float* dz_cur = P.dZ;
+        float* dz_nxt = P.dX;
         for (int l = L - 1; l >= 0; --l) {
             const int out = ly[l].out_dim, in = ly[l].in_dim;
-            const float* known = l == L - 1 ? nullptr : dz_max;
-            TR_TRY(gemm_dw(h, st, out, in, m, P.dZ, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, known));
-            TR_TRY(gemm_rm(h, false, false, m, in, out, P.dZ, out, P.W[l], in, 0.0f, P.dX, in, known));
+            const float* known = l == L - 1 ? nullptr : dz_max_cur;
+            TR_TRY(gemm_dw(h, st, out, in, m, dz_cur, P.X[l], p0 == 0 ? 0.0f : 1.0f, P.dW[l], P.partial, known));
             if (l == 0) {
-                hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, 0, m, I.D0, 1.0f, P.dIN0, I.D0);
+                TR_TRY(gemm_rm(h, false, false, m, in, out, dz_cur, out, P.W[l], in, 0.0f, dz_nxt, in, known));
+                hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, dz_nxt, in, 0, m, I.D0, 1.0f, P.dIN0, I.D0);
                 break;
             }
             const int outp = ly[l - 1].out_dim;
             const bool is_skip = (l == d->skip_layer);
-            if (is_skip) hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, P.dX, in, outp, m, I.D0, rs2, P.dIN0, I.D0);
-            TR_HIP(hipMemsetAsync(dz_max, 0, sizeof(float), st));
-            hipLaunchKernelGGL(k_relu_back, strip_grid(m, outp), dim3(256), 0, st, P.dX, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, P.dZ, P.db[l - 1], dz_max);
+            TR_HIP(hipMemsetAsync(dz_max_nxt, 0, sizeof(float), st));
+            RowsEpi eb;
+            memset(&eb, 0, sizeof(eb));
+            eb.m_pts = m; eb.n_act = outp; eb.sc = 1.0f; eb.Z = P.Z[l - 1]; eb.ldz = outp; eb.out = dz_nxt; eb.ld_out = outp;
+            eb.db = P.db[l - 1]; eb.amax_out = dz_max_nxt;
+            bool fused = false;
+            // (the skip layer also needs the plain product's input columns: it keeps the separate pass)
+            TR_TRY(gemm_rm(h, false, false, m, in, out, dz_cur, out, P.W[l], in, 0.0f, dz_nxt, in, known, is_skip ? kEpiPlain : kEpiReluBack,
+                           is_skip ? nullptr : &eb, &fused));
+            if (fused) {
+                float* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
+            } else {
+                if (is_skip) hipLaunchKernelGGL(k_add_cols, grid1((int64_t)m * I.D0), dim3(256), 0, st, dz_nxt, in, outp, m, I.D0, rs2, P.dIN0, I.D0);
+                hipLaunchKernelGGL(k_relu_back, strip_grid(m, outp), dim3(256), 0, st, dz_nxt, in, P.Z[l - 1], m, outp, is_skip ? rs2 : 1.0f, dz_cur,
+                                   P.db[l - 1], dz_max_nxt);
+            }
+            float* tm = dz_max_cur; dz_max_cur = dz_max_nxt; dz_max_nxt = tm;
         }
         hipLaunchKernelGGL(k_render_in_back, dim3((m + 255) / 256), dim3(256), 0, st, I, cp, cv, m, P.dIN0, d_pts ? d_pts + 3 * p0 : nullptr,
                            (d_view && I.nv) ? d_view + 3 * p0 : nullptr, d_nrm ? d_nrm + 3 * p0 : nullptr);
