@@ -389,6 +389,12 @@ int iron_shade_composite(const iron_shade_comp_nets* nets, float light, const fl
                          const float* ray_o, const float* ray_d, const float* points, const uint8_t* conv, int64_t n,
                          const iron_shade_comp_out* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* CU budget of the launches that follow (all streams, process-wide): the persistent kernels fill `n_cus` compute units instead of
+ * the whole device; n_cus <= 0 removes the limit.  Returns the device's CU count.  For callers that run two launch sequences side by
+ * side on two streams (iron_amd.raytracer.render_camera: hit shading beside the silhouette pass; no counterpart in the reference,
+ * whose render_camera, models/raytracer.py:778-814, is one sequence). */
+int32_t iron_set_cu_limit(int32_t n_cus);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): per-kernel device time from hipEvents recorded on the
  * caller's stream around each compute kernel.  Off by default.  iron_profile_read blocks on the

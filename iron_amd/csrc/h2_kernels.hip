@@ -67,7 +67,8 @@ int launch_sdf_values_h2(const iron_net* net, const float* x, int64_t n, float* 
     H2Meta m;
     m.n_hidden_layers = net->sdf.n_hidden_layers; m.skip_layer = net->sdf.skip_layer; m.scale = net->sdf.scale; m.b_last = net->sdf.b_last;
     const int64_t groups = (n + 127) / 128;
-    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);
+    const int64_t cus = cu_budget();
+    const unsigned grid = (unsigned)(groups < cus ? groups : cus);
     hipLaunchKernelGGL(k_sdf_values_h2, dim3(grid), dim3(256), kLdsH2Total + (IRON_H2_STAMP ? kLdsStampBytes : 0), st, net->h2_trace, m, x, n, out);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;

@@ -140,6 +140,8 @@ inline int hip_fail(hipError_t e) {
 }  // namespace iron
 
 namespace iron {
+int cu_total();    // CUs of the current device
+int cu_budget();   // CUs the launches of this moment may fill (iron_set_cu_limit; profile.hip)
 // hipEvent pair around one kernel launch when profiling is enabled (profile.hip)
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);

@@ -201,12 +201,7 @@ extern "C" int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, cons
     if (!pts4 || !view_dirs || (!alpha && !rgb)) return IRON_ERR_BAD_ARG;
     const NerfNetDev& r = nerf->nerf;
     const int64_t tiles = (n + kTile - 1) / kTile;
-    static int cus = 0;   // (one device per process)
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = cu_budget();
     const int64_t waves = (int64_t)cus * 4;
     const unsigned grid = (unsigned)(tiles < waves ? tiles : waves);
     hipStream_t st = (hipStream_t)stream;

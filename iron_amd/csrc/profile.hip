@@ -1,4 +1,5 @@
 // Per-kernel device timing with hipEvents on the caller's stream (diagnostics for bench.py).
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "iron_common.h"
@@ -59,4 +60,32 @@ extern "C" int iron_profile_read(double* ms, int64_t* launches) {
         (void)hipEventDestroy(p.b);
     }
     return rc;
+}
+
+// ---- CU budget -------------------------------------------------------------------------------------------------------------------
+// The persistent kernels size their grids to the chip (one workgroup per CU: the h2 kernels' LDS ring fills a CU).  A caller that
+// wants two launch sequences to run side by side on two streams (render_camera: shading of the hits beside the silhouette pass, which
+// is a chain of short latency-bound launches) gives each a share of the CUs for the duration of its launches.
+namespace iron {
+namespace {
+std::atomic<int> g_cu_limit{0};
+}
+int cu_total() {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cached = prop.multiProcessorCount;
+    return cached;
+}
+int cu_budget() {
+    const int total = cu_total(), lim = g_cu_limit.load(std::memory_order_relaxed);
+    return (lim > 0 && lim < total) ? lim : total;
+}
+}  // namespace iron
+
+extern "C" int32_t iron_set_cu_limit(int32_t n_cus) {
+    iron::g_cu_limit.store(n_cus > 0 ? n_cus : 0, std::memory_order_relaxed);
+    return iron::cu_total();
 }

@@ -876,15 +876,7 @@ static ShadeLayout shade_layout(int64_t n) {
     return L;
 }
 
-static int cu_count() {
-    static int cached = 0;
-    if (cached) return cached;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    cached = prop.multiProcessorCount;
-    return cached;
-}
+static int cu_count() { return cu_budget(); }
 
 static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st) {
     if (h2_sdf_usable(sdf)) {

@@ -503,14 +503,8 @@ static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const T
                                 hipStream_t st);
 
 static int resident_waves() {
-    // single-wave workgroups, one wave per SIMD (the kernels need > 256 registers per lane)
-    static int cached = 0;
-    if (cached) return cached;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
-    cached = prop.multiProcessorCount * 4;
-    return cached;
+    // single-wave workgroups, one wave per SIMD (the kernels need > 256 registers per lane); iron_set_cu_limit narrows it
+    return cu_budget() * 4;
 }
 
 static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const TraceArgs& a, const TraceWs& w, int64_t units,

@@ -16,6 +16,7 @@ There is no CPU path: tensors must be CUDA (ROCm) fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -575,6 +576,13 @@ def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_di
         return
     if is_training:
         return _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn)
+    _edge_blend(results, _edge_side_colours(results, camera, sdf_network, raytracer, color_network_dict, render_fn))
+
+
+def _edge_side_colours(results, camera, sdf_network, raytracer, color_network_dict, render_fn):
+    """First half of the inference edge pass: edge gradients -> the two side samples of every edge pixel (iron_edge_sides) -> traced
+    and shaded.  Reads the edge_* keys only; returns what the blend needs."""
+    n_edge = int(results["edge_uv"].shape[0])
     dev = results["edge_uv"].device
     edge_points = _lib.require_cuda_f32(results["edge_points"], "edge_points")
     edge_uv = _lib.require_cuda_f32(results["edge_uv"], "edge_uv")
@@ -589,16 +597,25 @@ def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_di
                                        weight.data_ptr(), _lib.stream_ptr(dev)))
     both = _side_rays(results, n_edge, sdf_network, raytracer, camera, side_uv, color_network_dict, render_fn, False)
     side_color = _lib.require_cuda_f32(both["color"], "color").reshape(2 * n_edge, 3)
+    return {"n_edge": n_edge, "edge_points": edge_points, "edge_uv": edge_uv, "pixel": pixel, "edge_grads": edge_grads, "weight": weight,
+            "side_color": side_color, "pos_neg_normal": both["normal"][both["convergent_mask"]]}
+
+
+def _edge_blend(results, ctx):
+    """Second half: iron_edge_blend writes colour, normal, uv and point of the edge pixels into `results`."""
+    dev = ctx["edge_uv"].device
+    n_edge = ctx["n_edge"]
     for k in ("color", "normal", "uv", "points"):
         if not results[k].is_contiguous():
             results[k] = results[k].contiguous()
     n_pixels = results["color"].numel() // 3
+    lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(lib.iron_edge_blend(side_color.data_ptr(), weight.data_ptr(), edge_grads.data_ptr(), edge_uv.data_ptr(),
-                                       edge_points.data_ptr(), pixel.data_ptr(), n_edge, n_pixels, results["color"].data_ptr(),
-                                       results["normal"].data_ptr(), results["uv"].data_ptr(), results["points"].data_ptr(),
-                                       _lib.stream_ptr(dev)))
-    results["edge_pos_neg_normal"] = both["normal"][both["convergent_mask"]]
+        _lib.check(lib.iron_edge_blend(ctx["side_color"].data_ptr(), ctx["weight"].data_ptr(), ctx["edge_grads"].data_ptr(),
+                                       ctx["edge_uv"].data_ptr(), ctx["edge_points"].data_ptr(), ctx["pixel"].data_ptr(), n_edge, n_pixels,
+                                       results["color"].data_ptr(), results["normal"].data_ptr(), results["uv"].data_ptr(),
+                                       results["points"].data_ptr(), _lib.stream_ptr(dev)))
+    results["edge_pos_neg_normal"] = ctx["pos_neg_normal"]
 
 
 def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn):
@@ -630,11 +647,69 @@ def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_
 
 def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes=False, handle_edges=True,
                   is_training=False, depth_edge_mask=None):
-    """raytracer.py:778-814 (`depth_edge_mask`: see raytrace_camera)."""
+    """raytracer.py:778-814 (`depth_edge_mask`: see raytrace_camera).
+    Inference with handle_edges and the fused GGX render_fn runs the hit shading and the silhouette pass side by side on two streams
+    (_render_camera_overlapped); IRON_EDGE_OVERLAP=0 keeps them in sequence."""
+    if (handle_edges and not is_training and EDGE_OVERLAP and getattr(render_fn, "iron_fused_ggx", None) is not None
+            and camera.K.is_cuda):
+        return _render_camera_overlapped(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes, depth_edge_mask)
     results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=50000, fill_holes=fill_holes,
                               detect_edges=handle_edges, depth_edge_mask=depth_edge_mask)
     render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=is_training,
                             max_num_pts=320000)
     if handle_edges and results["edge_mask"].sum() > 0:
         render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, render_fn, is_training=is_training)
+    return results
+
+
+# ---- hit shading beside the side rays of the silhouette pass -----------------------------------------------------------------------
+# The second half of an inference frame's silhouette pass (two side rays per edge pixel: generated, traced through <= 17 + 16 + ~10
+# dependent SDF evaluations, shaded) is a latency chain on a few thousand rays -- ~6 ms per 800x800 frame during which some 30
+# workgroups are busy and the rest of the chip idles.  It reads the edge_* maps only; the shading of the hits reads the traced maps
+# only.  They run on two streams, each on its share of the CUs (iron_set_cu_limit: the persistent kernels fill one CU per workgroup,
+# a full-width shading launch would leave the side stream nothing; measured with tools/cu_share.py).  The surface walk that finds the
+# edge points stays in front of both, at full width: it is ~250 workgroup-tiles of work on the depth-edge candidates, and the hits
+# are shaded with the edge pixels already out of the convergent mask, exactly the reference's order (raytracer.py:586-588, 800-812).
+EDGE_OVERLAP = os.environ.get("IRON_EDGE_OVERLAP", "1") != "0"
+EDGE_SIDE_CUS = int(os.environ.get("IRON_EDGE_SIDE_CUS", "48"))   # CUs of the side-ray stream (one workgroup traces 128 rays)
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
+def _render_camera_overlapped(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes, depth_edge_mask):
+    results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=50000, fill_holes=fill_holes, detect_edges=True,
+                              depth_edge_mask=depth_edge_mask)
+    if int(results["edge_uv"].shape[0]) == 0:
+        render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=False, max_num_pts=320000)
+        return results
+    dev = results["points"].device
+    lib = _lib.load()
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    located = torch.cuda.Event()
+    located.record(main)
+    n_cu = int(lib.iron_set_cu_limit(0))
+    side_cus = max(1, min(EDGE_SIDE_CUS, n_cu // 2))
+    try:
+        lib.iron_set_cu_limit(n_cu - side_cus)
+        render_normal_and_color(results, sdf_network, color_network_dict, render_fn, is_training=False, max_num_pts=320000)
+        lib.iron_set_cu_limit(side_cus)
+        with torch.cuda.stream(side):
+            side.wait_event(located)
+            ctx = _edge_side_colours(results, camera, sdf_network, raytracer, color_network_dict, render_fn)
+            done = torch.cuda.Event()
+            done.record(side)
+    finally:
+        lib.iron_set_cu_limit(0)
+    main.wait_event(done)
+    for v in ctx.values():   # produced on the side stream, consumed (and possibly released) on the caller's
+        if torch.is_tensor(v) and v.is_cuda:
+            v.record_stream(main)
+    _edge_blend(results, ctx)
     return results

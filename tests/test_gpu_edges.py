@@ -146,3 +146,36 @@ def test_locate_edge_points_empty_mask():
     out = locate_edge_points(cam, pts, nets["sdf_network"], 16, 1e-3, 5e-2, mask=torch.zeros(16, 16, dtype=torch.bool, device="cuda"))
     assert out["edge_points"].shape == (0, 3) and out["edge_uv"].shape == (0, 2)
     assert out["edge_pixel_idx"].numel() == 0 and not bool(out["edge_mask"].any())
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("scene,size", [("S0", 256), ("S1", 400)])
+def test_overlapped_edge_pass_equals_the_sequential_one(scene, size):
+    """render_camera(handle_edges=True) at inference shades the hits on one stream and traces + shades the silhouette's side rays on
+    another (raytracer._render_camera_overlapped, iron_set_cu_limit): every key of the result must equal the one-stream order bit
+    for bit, twice in a row (the second frame reuses the side stream and whatever the allocator handed back), and the CU budget
+    must be lifted again afterwards."""
+    from iron_amd import raytracer as RT
+    dev = torch.device("cuda", 0)
+    nets = {k: v.to(dev) for k, v in scenes.build_networks(scene).items()}
+    K, W2C = scenes.fixture_camera_matrices(size, size)
+    cam = Camera(size, size, K.to(dev), W2C.to(dev))
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    old = RT.EDGE_OVERLAP
+    try:
+        RT.EDGE_OVERLAP = False
+        want = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+        RT.EDGE_OVERLAP = True
+        tracer = RayTracer()
+        for _ in range(2):
+            got = render_camera(cam, nets["sdf_network"], tracer, nets, fn, fill_holes=True, handle_edges=True)
+            torch.cuda.synchronize()
+            assert set(got) == set(want)
+            assert int(got["edge_mask"].sum()) > 0
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+    finally:
+        RT.EDGE_OVERLAP = old
+    lib = _lib.load()
+    total = lib.iron_set_cu_limit(0)
+    assert total >= 64 and lib.iron_set_cu_limit(0) == total
