@@ -619,7 +619,13 @@ def _edge_blend(results, ctx):
 
 
 def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn):
-    pixel = results["edge_pixel_idx"]
+    prep = _edge_training_prepare(results, camera, sdf_network)
+    both = _side_rays(results, prep["n_edge"], sdf_network, raytracer, camera, prep["side_uv"], color_network_dict, render_fn, True)
+    _edge_training_finish(results, prep, both)
+
+
+def _edge_training_prepare(results, camera, sdf_network):
+    """Edge points re-attached to the SDF parameters, their projection, and the (non-differentiable) side samples."""
     anchor = results["edge_points"]
     centre = results["edge_uv"].floor() + 0.5
     sdf_at_edge, _, grads = sdf_network.get_all(anchor, is_training=True)
@@ -631,18 +637,22 @@ def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_
     in_plane = (unit.unsqueeze(1) * camera.W2C[:2, :3].unsqueeze(0)).sum(dim=-1)   # first two rows of the camera-space normal
     in_plane = in_plane / (in_plane.norm(dim=-1, keepdim=True) + 1e-10)
     offset = PIXEL_RADIUS * in_plane
-    n_edge = anchor.shape[0]
-    both = _side_rays(results, n_edge, sdf_network, raytracer, camera, torch.cat([centre - offset, centre + offset], dim=0),
-                      color_network_dict, render_fn, True)
+    return {"n_edge": int(anchor.shape[0]), "centre": centre, "grads": grads, "moving": moving, "moving_uv": moving_uv,
+            "in_plane": in_plane, "side_uv": torch.cat([centre - offset, centre + offset], dim=0)}
+
+
+def _edge_training_finish(results, prep, both):
+    pixel = results["edge_pixel_idx"]
+    n_edge, centre, in_plane = prep["n_edge"], prep["centre"], prep["in_plane"]
     # circular-segment area on the positive side of a chord at signed distance h from the centre, as a fraction of the disc
-    h = ((moving_uv - centre) * in_plane).sum(dim=-1)
+    h = ((prep["moving_uv"] - centre) * in_plane).sum(dim=-1)
     angle = 2 * torch.arccos((h / PIXEL_RADIUS).clamp(min=0.0, max=1.0))
     w = (1.0 - (angle - torch.sin(angle)) / (2.0 * np.pi)).unsqueeze(-1)
     results["color"].view(-1, 3)[pixel] = both["color"][:n_edge] * w + both["color"][n_edge:] * (1.0 - w)
-    results["normal"].view(-1, 3)[pixel] = grads
+    results["normal"].view(-1, 3)[pixel] = prep["grads"]
     results["edge_pos_neg_normal"] = both["normal"][both["convergent_mask"]]
-    results["uv"].view(-1, 2)[pixel] = moving_uv.detach()
-    results["points"].view(-1, 3)[pixel] = moving.detach()
+    results["uv"].view(-1, 2)[pixel] = prep["moving_uv"].detach()
+    results["points"].view(-1, 3)[pixel] = prep["moving"].detach()
 
 
 def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes=False, handle_edges=True,
