@@ -12,6 +12,8 @@ python3 bench.py --workload c2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err" || 
 echo "c2 bench done"
 python3 bench.py --workload c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err" || { tail -5 "$OUT/bench_c3.err"; exit 1; }
 echo "c3 bench done"
+python3 bench.py --edges --no-extras > "$OUT/bench_c1_edges.json" 2> "$OUT/bench_c1_edges.err" || { tail -5 "$OUT/bench_c1_edges.err"; exit 1; }
+echo "c1 --edges bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c1" -o c1 -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/trace_c1.log" 2>&1 || { tail -5 "$OUT/trace_c1.log"; exit 1; }
 echo "c1 trace done"

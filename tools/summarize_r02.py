@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "r02")
 out = os.path.join(ROOT, "profiles")
-names = {"c1": "r02_bench_1gpu.json", "c2": "r02_bench_c2_neus_forward.json", "c3": "r02_bench_c3_train_step.json"}
+names = {"c1": "r02_bench_1gpu.json", "c1_edges": "r02_bench_1gpu_edges.json", "c2": "r02_bench_c2_neus_forward.json", "c3": "r02_bench_c3_train_step.json"}
 for k, n in names.items():
     p = os.path.join(src, "bench_%s.json" % k)
     if os.path.exists(p):
