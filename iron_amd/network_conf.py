@@ -20,7 +20,21 @@ class PointLightNetwork(nn.Module):
         return self.light
 
     def set_light(self, light):
-        self.light.data.fill_(light)
+        with torch.no_grad():
+            self.light.fill_(light)   # in place on the parameter (not through .data): the version counter moves, host_light() sees it
+
+    def host_light(self) -> float:
+        """The scalar as a host float, read from the device once per (storage, version) of the parameter: the fused inference
+        shading passes it by value, and reading it every frame is the frame's one host sync (it stalls the launch queue behind the
+        whole trace).  A write through `.data` does not move the version counter: call invalidate() after one."""
+        key = (self.light.data_ptr(), self.light._version, str(self.light.device))
+        if getattr(self, "_host_light_key", None) != key:
+            self._host_light_value = float(self.light.detach())
+            self._host_light_key = key
+        return self._host_light_value
+
+    def invalidate(self) -> None:
+        self._host_light_key = None
 
     def get_light(self):
         return self.light.data.clone().detach()

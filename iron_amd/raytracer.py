@@ -257,8 +257,15 @@ class Camera(object):
 
     def get_uv(self):
         """Pixel centres [H,W,2] (raytracer.py:300-303)."""
-        u, v = np.meshgrid(np.arange(self.W), np.arange(self.H))
-        return torch.from_numpy(np.stack((u, v), axis=-1).astype(np.float32)).to(self.device) + 0.5
+        # built on the device (a fresh tensor per call, as in the reference: callers write into it): the reference's numpy meshgrid
+        # + .to(device) is a synchronous 5 MB host copy per 800x800 frame that also drains the stream -- the next frame's trace could
+        # not be queued behind the current frame's shading (1.9 ms of idle GPU per frame, tools/host_timeline.py)
+        if self.device.type != "cuda":
+            u, v = np.meshgrid(np.arange(self.W), np.arange(self.H))
+            return torch.from_numpy(np.stack((u, v), axis=-1).astype(np.float32)).to(self.device) + 0.5
+        u = torch.arange(self.W, dtype=torch.float32, device=self.device) + 0.5
+        v = torch.arange(self.H, dtype=torch.float32, device=self.device) + 0.5
+        return torch.stack((u.unsqueeze(0).expand(self.H, self.W), v.unsqueeze(1).expand(self.H, self.W)), dim=-1)
 
     def project(self, points):
         """points [...,3] -> uv [...,2] (raytracer.py:305-325): homogeneous point through W2C and K, perspective division.  Written

@@ -147,7 +147,7 @@ class CompRenderFn:
         t1, t2 = self.renderer._tables_on(dev)
         ws_bytes = lib.iron_shade_composite_workspace_bytes(n)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        light = float(color_network_dict["point_light_network"]().detach())
+        light = _host_light(color_network_dict["point_light_network"])
         with torch.cuda.device(dev):
             _lib.check(lib.iron_shade_composite(C.byref(nets), light, t1.data_ptr(), t2.data_ptr(), ray_o.data_ptr(), ray_d.data_ptr(),
                                                 pts.data_ptr(), conv.data_ptr(), n, C.byref(so), ws.data_ptr(), ws_bytes,
@@ -214,12 +214,19 @@ class GGXRenderFn:
         t1, t2 = self.renderer._tables_on(dev)
         ws_bytes = lib.iron_shade_workspace_bytes(n)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        light = float(color_network_dict["point_light_network"]().detach())
+        light = _host_light(color_network_dict["point_light_network"])
         with torch.cuda.device(dev):
             _lib.check(lib.iron_shade_ggx(C.byref(nets), light, 1 if self.is_metal else 0, t1.data_ptr(), t2.data_ptr(),
                                           ray_o.data_ptr(), ray_d.data_ptr(), pts.data_ptr(), conv.data_ptr(), n,
                                           C.byref(so), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)))
         return bufs
+
+
+def _host_light(module) -> float:
+    """The light scalar by value: cached per parameter version when the module offers it (network_conf.PointLightNetwork), read from
+    the device otherwise (any callable returning a 0-dim tensor, as the reference's)."""
+    cached = getattr(module, "host_light", None)
+    return cached() if cached is not None else float(module().detach())
 
 
 def make_render_fn(renderer, is_metal: bool = False) -> GGXRenderFn:
