@@ -182,8 +182,10 @@ class ShardedRenderer:
     def _pix(self, H, W, device):
         key = (H, W, str(device))
         if key not in self._pix_cache:
-            lists = [tile_pixels(H, W, self.tile, self.world, r) for r in range(self.world)]
-            mine = lists[self.rank].to(device)
+            # every rank's pixel list, resident on the device: assemble_views indexes with them every frame (a host list would be
+            # one synchronous host-to-device copy per rank and frame on rank 0)
+            lists = [tile_pixels(H, W, self.tile, self.world, r).to(device) for r in range(self.world)]
+            mine = lists[self.rank]
             uv = torch.stack(((mine % W).float() + 0.5, (mine // W).float() + 0.5), dim=-1)  # raytracer.py:300-303
             self._pix_cache[key] = (lists, mine, uv)
         return self._pix_cache[key]
@@ -312,6 +314,9 @@ def render_emulated(world: int, cameras, sdf_network, color_network_dict, render
     rs = [ShardedRenderer(sdf_network, color_network_dict, raytracer_factory(), render_fn, tile=tile, chunk=chunk, world=world, rank=r)
           for r in range(world)]
     ms = [0.0] * world
+    for r in rs:   # the pixel lists are per-resolution setup (cached by a long-lived renderer), not part of a step
+        r._pix(cameras[0].H, cameras[0].W, cameras[0].device)
+    torch.cuda.synchronize(cameras[0].device)
 
     def timed(r, fn, *a):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
