@@ -62,7 +62,10 @@ def test_eight_tile_shards_equal_render_camera_and_balance(res, yaw):
     ref = render_camera(cam, sdf, RayTracer(), nets, fn, fill_holes=False, handle_edges=False)
     t_frame = _frame_ms(lambda: render_camera(cam, sdf, RayTracer(), nets, fn, fill_holes=False, handle_edges=False))
     render_emulated(8, [cam], sdf, nets, fn, RayTracer)  # warm the per-shard launches
-    out, ms, ms_asm = render_emulated(8, [cam], sdf, nets, fn, RayTracer)
+    runs = [render_emulated(8, [cam], sdf, nets, fn, RayTracer) for _ in range(3)]
+    out = runs[-1][0]
+    ms = [min(r[1][k] for r in runs) for k in range(8)]   # per shard: best of 3 (an allocator stall inflates a single run 3-10x)
+    ms_asm = min(r[2] for r in runs)
     _check_equal(out, ref)
     # invariants of the assembled image (the ones test_fullsize_invariants holds the unsharded frame to)
     conv = out["convergent_mask"][0]
