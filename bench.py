@@ -130,6 +130,19 @@ def _c3_cpu_baseline(threads, size=128):
             "rays_fraction_of_workload": (size / 512.0) ** 2}
 
 
+def _recorded_traffic(key):
+    """HBM bytes per launch of a dominant kernel from the committed PMC passes (tools/pmc_r02.sh -> profiles/hbm_traffic.json), or None."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        e = json.load(open(tp)).get(key)
+    except OSError:
+        return None, None
+    if not e:
+        return None, None
+    return e["bytes_per_launch"], ("profiles/hbm_traffic.json [%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                   "(gfx950 corrections applied), NOT re-measured in this run; %s" % (key, e.get("source", "")))
+
+
 def _gemm_roofline():
     """HBM roofline of the backward's dominant kernel, measured here: the layer product Z = X W^T at the shape of one SDF chunk
     (131 072 rows = 65 536 points x {value, tangent}, 256 -> 256) through iron_train_gemm on the current stream, hipEvents around
@@ -158,8 +171,9 @@ def _gemm_roofline():
     sec = e0.elapsed_time(e1) / 20 / 1e3
     bytes_alg = 4.0 * R_ * (K_ + N_)
     flop = 2.0 * R_ * K_ * N_
+    traffic, traffic_src = _recorded_traffic("c3_gemm_rows_probe")
     return {"bound": "hbm", "kernel": "k_gemm_rows<2> (+ k_gemm_pack_b): layer product Z = X W^T, 131072 x 256 x 256, of iron_sdf_backward", "achieved": bytes_alg / sec / 1e9,
-            "peak": 8000.0, "unit": "GB/s", "frac": bytes_alg / sec / 8e12, "traffic": None,
+            "peak": 8000.0, "unit": "GB/s", "frac": bytes_alg / sec / 8e12, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": sec * 1e3, "tflops_fp32_equivalent": flop / sec / 1e12,
             "note": "bytes = 4 B x rows x (K + N): A read once, C written once; 43 FLOP per byte at K = N = 256 is below the split-fp16 "
                     "ridge (833 TFLOP/s / 8 TB/s = 104), so HBM is the bound of a layer-wise backward"}
@@ -189,8 +203,10 @@ def secondary_workload(a):
             pts = 4096 * 128
             sec = kernels["sdf_grad"]["ms_avg"] / 1e3
             ach = FLOP_SDF_GRAD * pts / sec
+            traffic, traffic_src = _recorded_traffic("c2_sdf_grad")
             roof = {"bound": "mfma", "kernel": "k_sdf_grad_h2 (get_all: value + analytic gradient + 256 features at 4096 x 128 points)",
-                    "achieved": ach / 1e12, "peak": PEAK_F16_MFMA / 3.0 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_F16_MFMA / 3.0), "traffic": None,
+                    "achieved": ach / 1e12, "peak": PEAK_F16_MFMA / 3.0 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_F16_MFMA / 3.0), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "flop_per_unit": FLOP_SDF_GRAD, "units_per_launch": pts, "avg_launch_ms": kernels["sdf_grad"]["ms_avg"],
                     "peak_basis": "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate MAC",
                     "note": "algorithmic FLOP per point = 2 x (524 544 forward + 459 008 input-gradient) MAC (SURVEY 8d); the kernel evaluates the "
