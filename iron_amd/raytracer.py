@@ -530,8 +530,10 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
             torch.split(results["ray_d"].reshape(-1, 3), max_num_pts, dim=0),
             torch.split(results["ray_o"].reshape(-1, 3), max_num_pts, dim=0),
             torch.split(results["convergent_mask"].reshape(-1), max_num_pts, dim=0)):
-        if mask_split.any():
-            points_split, ray_d_split, ray_o_split = points_split[mask_split], ray_d_split[mask_split], ray_o_split[mask_split]
+        # the hits listed ONCE (x[mask] lists them again at every use: a nonzero and a host sync each)
+        hit_index = mask_split.nonzero(as_tuple=True)[0]
+        if hit_index.numel() > 0:
+            points_split, ray_d_split, ray_o_split = (x.index_select(0, hit_index) for x in (points_split, ray_d_split, ray_o_split))
             sdf_split, feature_split, normal_split = sdf_network.get_all(points_split, is_training=is_training)
             if is_training:
                 points_split = reparam_points(points_split, normal_split.detach(), -ray_d_split.detach(), sdf_split)
@@ -539,8 +541,12 @@ def render_normal_and_color(results, sdf_network, color_network_dict, render_fn,
             e = torch.zeros(0, dtype=torch.float32, device=points_split.device)
             points_split = ray_d_split = ray_o_split = normal_split = feature_split = e
         with torch.set_grad_enabled(is_training):
-            r = render_fn(mask_split, color_network_dict, ray_o_split, ray_d_split, points_split, normal_split,
-                          feature_split)
+            if getattr(render_fn, "iron_takes_hit_index", False):
+                r = render_fn(mask_split, color_network_dict, ray_o_split, ray_d_split, points_split, normal_split, feature_split,
+                              hit_index=hit_index)
+            else:
+                r = render_fn(mask_split, color_network_dict, ray_o_split, ray_d_split, points_split, normal_split,
+                              feature_split)
         if merge is None:
             merge = {k: [v] for k, v in r.items()} if r is not None else {}
         else:

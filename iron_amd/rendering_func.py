@@ -101,26 +101,27 @@ class CompRenderFn:
     def __init__(self, renderer):
         self.renderer = renderer
 
-    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features):
+    iron_takes_hit_index = True   # see GGXRenderFn.__call__
+
+    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features, hit_index=None):
         dots_sh = list(interior_mask.shape)
         dev = interior_mask.device
         rgb = torch.zeros(dots_sh + [3], dtype=torch.float32, device=dev)
         out = {k: rgb.clone() for k in self._VEC}
         for k in self._SCALAR:
             out[k] = rgb[..., 0:1].clone()
-        if interior_mask.any():
+        if points.shape[0] > 0:   # the rows handed over are the mask's hits (render_surface.py:159-170)
+            idx = hit_index if hit_index is not None else interior_mask.reshape(-1).nonzero(as_tuple=True)[0]
             normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
             params = get_materials_comp(color_network_dict, points, normals, features)
             light = color_network_dict["point_light_network"]()  # a Parameter: trainable under is_training
             res = self.renderer(light, (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d, params=params)
-            out["color"][interior_mask] = res["rgb"]
-            out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
-            out["specular_color"][interior_mask] = res["specular_rgb"]
-            out["metallic_rgb"][interior_mask] = res["metallic_rgb"]
-            out["dielectric_rgb"][interior_mask] = res["dielectric_rgb"]
+            values = {"color": res["rgb"], "diffuse_color": res["diffuse_rgb"], "specular_color": res["specular_rgb"],
+                      "metallic_rgb": res["metallic_rgb"], "dielectric_rgb": res["dielectric_rgb"], "normal": normals}
             for k in ("diffuse_albedo", "specular_albedo") + self._SCALAR:
-                out[k][interior_mask] = params[k]
-            out["normal"][interior_mask] = normals
+                values[k] = params[k]
+            for k, v in values.items():   # one list of hit positions for all fourteen scatters
+                out[k].view(-1, out[k].shape[-1])[idx] = v
         return out
 
 
@@ -171,25 +172,28 @@ class GGXRenderFn:
         self.is_metal = is_metal
 
     # -- generic path: same steps as the reference closure, each through its HIP operator -----------
-    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features):
+    iron_takes_hit_index = True   # render_normal_and_color hands over the hit positions it has already listed
+
+    def __call__(self, interior_mask, color_network_dict, ray_o, ray_d, points, normals, features, hit_index=None):
+        """`hit_index` (optional, beyond the reference's signature): int64 positions of the True entries of the flattened mask.  Every
+        `x[mask] = v` lists the mask again (a nonzero + a host sync each); the seven scatters below share one list instead."""
         dots_sh = list(interior_mask.shape)
         dev = interior_mask.device
         rgb = torch.zeros(dots_sh + [3], dtype=torch.float32, device=dev)
         out = {k: rgb.clone() for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo",
                                         "specular_albedo", "normal")}
         out["specular_roughness"] = rgb[..., 0].clone()
-        if interior_mask.any():
+        if points.shape[0] > 0:   # the rows handed over ARE the mask's hits (render_surface.py:117-126): no device query needed
+            idx = hit_index if hit_index is not None else interior_mask.reshape(-1).nonzero(as_tuple=True)[0]
             normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
             params = get_materials(color_network_dict, points, normals, features, is_metal=self.is_metal)
             light = color_network_dict["point_light_network"]()  # a Parameter: trainable under is_training
             res = self.renderer(light, (points - ray_o).norm(dim=-1, keepdim=True), normals, -ray_d, params=params)
-            out["color"][interior_mask] = res["rgb"]
-            out["diffuse_color"][interior_mask] = res["diffuse_rgb"]
-            out["specular_color"][interior_mask] = res["specular_rgb"]
-            out["diffuse_albedo"][interior_mask] = params["diffuse_albedo"]
-            out["specular_albedo"][interior_mask] = params["specular_albedo"]
-            out["specular_roughness"][interior_mask] = params["specular_roughness"].squeeze(-1)
-            out["normal"][interior_mask] = normals
+            for key, val in (("color", res["rgb"]), ("diffuse_color", res["diffuse_rgb"]), ("specular_color", res["specular_rgb"]),
+                             ("diffuse_albedo", params["diffuse_albedo"]), ("specular_albedo", params["specular_albedo"]),
+                             ("normal", normals)):
+                out[key].view(-1, 3)[idx] = val
+            out["specular_roughness"].view(-1)[idx] = params["specular_roughness"].squeeze(-1)
         return out
 
     # -- fused path used by render_normal_and_color ---------------------------------------------------
