@@ -4,6 +4,9 @@ pixels) on synthetic 800x800 views (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Both forms start N ranks, one per GPU: without WORLD_SIZE in the environment `--gpus N` (N > 1) makes this process a
+launcher -- it never touches the GPU, starts N fresh children of this script with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays rank 0's JSON line and exits non-zero if any rank does.
 
 Workload (config C1): scene S0 (seed-0 geometric-init SDF, `ggx` material nets), fixture camera
 rescaled to 800x800, tracer defaults, fill_holes=False, handle_edges=False, fp32.
@@ -66,7 +69,91 @@ def parse():
                          "the oracle timed on a bounded sample -- "
                          "c2 = stage-1 NeuS forward, 4096 rays x 128 samples per step; c3 = one stage-2 training step with edge "
                          "sampling at 512x512")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="N>1: only join the process group (IRON_BENCH_BACKEND, default nccl), all-reduce the rank count and print the "
+                         "line's launch fields -- the launcher's own test (tests/test_bench_launcher.py runs it on CPU over gloo)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a torchrun around it: this process becomes the launcher.  It has not touched the GPU
+    (importing torch does not; torch.cuda.device_count() does not initialise HIP on this image) and never will: it starts N fresh
+    children -- never an exec of a process that holds the device -- one rank per GPU, waits for all of them, relays rank 0's
+    stdout (the JSON line) and returns non-zero if any rank failed.  IRON_BENCH_ONE_GPU=1 puts every rank on cuda:0 (rehearsal
+    on a one-GPU box, with IRON_BENCH_BACKEND=gloo)."""
+    import subprocess
+    import threading
+    n = a.gpus
+    one_gpu = os.environ.get("IRON_BENCH_ONE_GPU", "0") == "1"
+    if not a.rendezvous_only and not one_gpu:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (IRON_BENCH_ONE_GPU=1 IRON_BENCH_BACKEND=gloo rehearses "
+                             "the %d-rank path on one card)" % (n, have, n))
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IRON_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    lines = []
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("[bench] rank %d exited with %d: stopping the other ranks" % (r, code), file=sys.stderr, flush=True)
+                for q in alive:          # exactly the processes started above, by handle
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join(timeout=5)
+    for line in lines:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in lines):
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def rendezvous_only(a, world, rank):
+    """The launch protocol without a render: join the group, count the ranks with an all-reduce, print the launch fields."""
+    import torch.distributed as dist
+    backend = os.environ.get("IRON_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dev = torch.device("cuda", 0 if os.environ.get("IRON_BENCH_ONE_GPU", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+    else:
+        dist.init_process_group(backend)
+        one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": a.gpus, "ranks_seen": dist.get_world_size(), "ranks_counted": int(one.item()),
+                          "backend": backend, "launcher": os.environ.get("IRON_BENCH_LAUNCHER", "torchrun")}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _host_threads():
@@ -298,11 +385,17 @@ def main():
     a = parse()
     if a.workload != "c1":
         return secondary_workload(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.rendezvous_only:
+        if world < 2:
+            raise SystemExit("--rendezvous-only is the N>1 launch check")
+        return rendezvous_only(a, world, rank)
     import torch.distributed as dist
     # IRON_BENCH_BACKEND=gloo + IRON_BENCH_ONE_GPU=1: rehearse the N>1 path with all ranks on one card
     backend = os.environ.get("IRON_BENCH_BACKEND", "nccl")
@@ -477,6 +570,9 @@ def main():
             "metric": "Mrays/s sphere-trace+GGX shade, drv/dragon 800x800 (synthetic S0)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": a.scaling if world > 1 else "weak", "other_scaling": other, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ranks": {"world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+                      "launcher": (os.environ.get("IRON_BENCH_LAUNCHER", "torchrun") if world > 1 else None),
+                      "all_ranks_on_one_gpu": bool(one_gpu and world > 1)},
             "mlp_core": os.environ.get("IRON_MLP_CORE", "h2") + (" (fp32-accurate split-fp16 MFMA, LDS weight ring)" if not os.environ.get("IRON_MLP_CORE", "h2").startswith("f") else " (exact fp32 MFMA)"),
             "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
                                    "sphere-trace + GGX shade, fp32%s" % (a.scene, a.res, a.res, " + hole filling + silhouette edge sampling" if a.edges else ""),
