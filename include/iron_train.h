@@ -10,15 +10,18 @@
  *
  * Method: the hit points of one call are processed as a batch, layer by layer, in fp32.  The forward activations are
  * recomputed from the inputs and kept in the caller's workspace (HBM is 288 GB: 37 KB per point for the SDF net), the
- * per-layer products (Z = X W^T, dX = dZ W, dW = dZ^T X with K = number of points) are plain SGEMMs issued to rocBLAS,
+ * per-layer products (Z = X W^T, dX = dZ W, dW = dZ^T X with K = number of points) are this library's own split-fp16 MFMA GEMMs
+ * (csrc/gemm_h2.h, exported as iron_train_gemm; no BLAS library is linked),
  * everything between them (positional encoding and its derivative, softplus-100 first and second derivative, the
  * forward-mode tangent rows that carry d(normal)/d(theta), weight-norm fold and its backward, column sums, the GGX
  * derivative) is hand-written HIP.
  *
  * Conventions as iron_hip.h: device pointers, fp32 row-major contiguous, caller-owned buffers and workspace, work enqueued
  * on `stream`, IRON_OK or a negative iron_status.  Parameter gradients are WRITTEN (not accumulated) to the d_* pointers
- * of each layer.  Threading: the two GEMM-based entries (iron_sdf_backward, iron_render_backward) share one rocBLAS handle per
- * device and serialise their host-side enqueue per process; the work itself runs asynchronously on the caller's stream.
+ * of each layer.  Threading: the two GEMM-based entries (iron_sdf_backward, iron_render_backward) serialise their host-side
+ * enqueue per process; the work itself runs asynchronously on the caller's stream.
+ * Operand range: every GEMM operand is split into two fp16 pieces; gradient operands are rescaled by a power of two from their
+ * absolute maximum, all other operands (weights, recomputed activations, tangent rows) must stay below 65 504 in magnitude.
  */
 #ifndef IRON_TRAIN_H
 #define IRON_TRAIN_H
@@ -174,7 +177,7 @@ int iron_train_gemm(int32_t op_a, int32_t op_b, int32_t m, int32_t n, int32_t k,
                     float beta, float* C, int32_t ldc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Diagnostics: last hipError_t seen by this library on the calling thread (iron_train_last_blas_status: kept for ABI
- * stability from the rocBLAS days, always 0). */
+ * stability, always 0: the library links no BLAS). */
 int iron_train_last_hip_error(void);
 int iron_train_last_blas_status(void);
 

@@ -134,7 +134,7 @@ SYMBOLS = {
                                  C.POINTER(iron_shade_out), _P, _SZ, _P]),
 }
 
-# ---- libiron_train.so (include/iron_train.h): backward passes, loaded on first use (it pulls rocBLAS in) ----
+# ---- libiron_train.so (include/iron_train.h): backward passes, loaded on first use ----
 class iron_train_layer(C.Structure):
     _fields_ = [("weight_v", C.c_void_p), ("weight_g", C.c_void_p), ("bias", C.c_void_p), ("d_weight_v", C.c_void_p),
                 ("d_weight_g", C.c_void_p), ("d_bias", C.c_void_p), ("out_dim", C.c_int32), ("in_dim", C.c_int32)]
@@ -218,7 +218,7 @@ def check_train(status: int) -> None:
         lib = load_train()
         msg = load().iron_strerror(status).decode()
         if status == -3:
-            msg += " [hipError_t=%d rocblas_status=%d]" % (lib.iron_train_last_hip_error(), lib.iron_train_last_blas_status())
+            msg += " [hipError_t=%d]" % lib.iron_train_last_hip_error()
         raise IronError("libiron_train: %s" % msg)
 
 

@@ -1,7 +1,7 @@
 """torch.autograd.Function wrappers that make the HIP operators trainable (BASELINE config C3).
 
 The reference trains by running its ordinary torch modules under autograd (render_surface.py:533-653).  Here each
-operator's forward is the inference HIP kernel (libiron_hip.so) and its backward is the closed-form HIP / rocBLAS pass of
+operator's forward is the inference HIP kernel (libiron_hip.so) and its backward is the closed-form HIP pass (hand-written split-fp16 MFMA GEMMs, no BLAS) of
 libiron_train.so (include/iron_train.h):
 
     SDFGetAllFn      SDFNetwork.get_all(is_training=True) / .gradient       models/fields.py:106-137 (second order)

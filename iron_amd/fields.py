@@ -8,7 +8,7 @@ that is rebuilt whenever a parameter's version counter changes.
 
 There is no CPU / eager compute path here: tensors must be CUDA (ROCm) fp32.
 SDFNetwork.get_all(is_training=True) / .gradient and RenderingNetwork.forward are differentiable through
-iron_amd.autograd (HIP forward + closed-form HIP / rocBLAS backward); NeRF is forward only.
+iron_amd.autograd (HIP forward + closed-form HIP backward); NeRF is forward only.
 """
 from __future__ import annotations
 

@@ -674,7 +674,7 @@ def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn,
     Inference with handle_edges and the fused GGX render_fn runs the hit shading and the silhouette pass side by side on two streams
     (_render_camera_overlapped); IRON_EDGE_OVERLAP=0 keeps them in sequence."""
     if (handle_edges and not is_training and EDGE_OVERLAP and getattr(render_fn, "iron_fused_ggx", None) is not None
-            and camera.K.is_cuda):
+            and camera.K.is_cuda and not _has_stream_bound_scratch(color_network_dict)):
         return _render_camera_overlapped(camera, sdf_network, raytracer, color_network_dict, render_fn, fill_holes, depth_edge_mask)
     results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=50000, fill_holes=fill_holes,
                               detect_edges=handle_edges, depth_edge_mask=depth_edge_mask)
@@ -696,6 +696,16 @@ def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn,
 EDGE_OVERLAP = os.environ.get("IRON_EDGE_OVERLAP", "1") != "0"
 EDGE_SIDE_CUS = int(os.environ.get("IRON_EDGE_SIDE_CUS", "48"))   # CUs of the side-ray stream (one workgroup traces 128 rays)
 _side_streams = {}
+
+
+def _has_stream_bound_scratch(color_network_dict) -> bool:
+    """A material net with a skip layer parks partial sums in a per-handle scratch indexed by workgroup (k_material_h2_skip):
+    launches on such a handle must be ordered on ONE stream (include/iron_hip.h).  The overlapped frame shades the hits and the
+    side rays with the same handles on two streams, so it is only taken when no net of the dict has a skip layer."""
+    for net in color_network_dict.values():
+        if len(getattr(net, "skip_in", ()) or ()) > 0 and not hasattr(net, "sdf"):
+            return True
+    return False
 
 
 def _side_stream(dev):

@@ -179,3 +179,42 @@ def test_overlapped_edge_pass_equals_the_sequential_one(scene, size):
     lib = _lib.load()
     total = lib.iron_set_cu_limit(0)
     assert total >= 64 and lib.iron_set_cu_limit(0) == total
+
+
+@torch.no_grad()
+def test_skip_layer_material_net_keeps_the_one_stream_order():
+    """the upstream 8-layer PE-10 skip-4 diffuse net (models/network_conf.py:60-71 / the `multi` branch :135-146)
+    parks partial sums in a per-handle scratch (k_material_h2_skip), so launches on it must stay on one stream.  render_camera must
+    not take the two-stream frame with such a net, and the result with IRON_EDGE_OVERLAP on equals the one with it off bit for bit."""
+    from iron_amd import raytracer as RT
+    from iron_amd.fields import RenderingNetwork
+    dev = torch.device("cuda", 0)
+    nets = {k: v.to(dev) for k, v in scenes.build_networks("S1").items()}
+    torch.manual_seed(5)
+    nets["diffuse_albedo_network"] = RenderingNetwork(d_in=9, d_out=3, d_feature=256, d_hidden=256, n_layers=8, multires=10, multires_view=4,
+                                                      mode="idr", squeeze_out=True, skip_in=(4,)).to(dev)
+    assert RT._has_stream_bound_scratch(nets)
+    plain = {k: v.to(dev) for k, v in scenes.build_networks("S1").items()}
+    assert not RT._has_stream_bound_scratch(plain)
+    size = 256
+    K, W2C = scenes.fixture_camera_matrices(size, size)
+    cam = Camera(size, size, K.to(dev), W2C.to(dev))
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    old, called = RT.EDGE_OVERLAP, []
+    orig = RT._render_camera_overlapped
+    try:
+        RT._render_camera_overlapped = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+        RT.EDGE_OVERLAP = False
+        want = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+        RT.EDGE_OVERLAP = True
+        for _ in range(2):
+            got = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+            torch.cuda.synchronize()
+            assert int(got["edge_mask"].sum()) > 0
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+        assert not called, "the two-stream frame was taken with a skip-layer material net"
+        assert float(want["diffuse_albedo"][want["convergent_mask"]].abs().max()) > 0
+    finally:
+        RT.EDGE_OVERLAP = old
+        RT._render_camera_overlapped = orig
