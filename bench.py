@@ -11,7 +11,7 @@ MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays rank 0's JSON line and exits non
 Workload (config C1): scene S0 (seed-0 geometric-init SDF, `ggx` material nets), fixture camera
 rescaled to 800x800, tracer defaults, fill_holes=False, handle_edges=False, fp32.
   N = 1 : one step = render_camera() of one 800x800 view through the drop-in operator surface.
-  N > 1 : rays sharded over the N ranks by interleaved 32x32 tiles; one MAX all-reduce of the per-chunk bisection
+  N > 1 : rays sharded over the N ranks by interleaved 8x8 tiles; one MAX all-reduce of the per-chunk bisection
           counts and one RCCL gather of the finished pixel records to rank 0 per step.
           --scaling weak (default): one step = N views (fixture pose orbited by k*45 deg, BASELINE config C4's shape),
           every view sharded over all ranks; per-GPU work is fixed -> "scaling": "weak".
@@ -45,6 +45,7 @@ PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2
 PEAK_F16_MFMA = 2.5e15          # dense f16/bf16 MFMA (the pipe the default "h2" core executes on)
 MFMA_FLOP_PER_EVAL_H2 = 3 * 2 * (7 * 256 * 256 + 2 * 8 * 3 * 16 * 32)   # executed: 3 f16 products per MAC, padded shapes
 MFMA_FLOP_PER_EVAL_F32 = 7488 * 4096 // 32
+SHARD_TILE = 8                  # interleaved tile edge of the N>1 sharding (iron_amd/sharding.py)
 
 
 def parse():
@@ -350,19 +351,34 @@ def cpu_baseline(scene: str, res: int):
             "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean())}
 
 
-def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms):
-    """One-GPU evidence for the multi-GPU target: the 8 (and 2, 4) tile-shards of the frame run one after the other on this
-    card through the phase methods ShardedRenderer.render() uses; T(frame) / max_r T(shard r) is the strong-scaling factor
-    load balance allows (kernel time only: the all-reduce, the gather and rank 0's un-tile come on top)."""
-    from iron_amd.sharding import render_emulated
-    out = {"frame_ms": frame_ms, "note": "T(frame) / max over shards of the shard's device time, shards run in turn on one card"}
+def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=6):
+    """One-GPU PREDICTION for the multi-GPU target (no collectives in it): for world = 2, 4, 8 every rank's tile shard of the frame is
+    run on this card the way the rank runs it -- its rank-local phases of ShardedRenderer (trace_begin -> trace_finish -> shade) back
+    to back, `steps` steps without a host sync in between -- and T(frame) / max_r T(rank r step) is the strong-scaling factor the
+    kernels and the host glue allow.  What an N-GPU step adds on top: the MAX all-reduce of 13 ints, the gather of 26 floats per
+    pixel to rank 0 and rank 0's un-tile (`assemble_ms`, measured here; factor_with_assemble includes it)."""
+    from iron_amd.sharding import ShardedRenderer, render_emulated
+    out = {"frame_ms": frame_ms, "tile": SHARD_TILE,
+           "note": "PREDICTION from one card: T(frame) / max over ranks of the rank's steady-state step (rank-local phases back to back, "
+                   "no collectives); factor_with_assemble adds rank 0's un-tile"}
     for world in (2, 4, 8):
-        render_emulated(world, [cam], sdf, nets, fn, tracer_factory)     # warm: allocator blocks of this shard size
-        runs = [render_emulated(world, [cam], sdf, nets, fn, tracer_factory) for _ in range(3)]
-        ms = [min(r[1][k] for r in runs) for k in range(world)]         # per shard: best of 3 (an allocator stall inflates single runs)
-        asm = min(r[2] for r in runs)
-        out["n%d" % world] = {"shard_ms": [round(x, 3) for x in ms], "max_shard_ms": max(ms), "assemble_ms": asm,
-                              "factor": frame_ms / max(ms)}
+        ms = []
+        for r in range(world):
+            sh = ShardedRenderer(sdf, nets, tracer_factory(), fn, tile=SHARD_TILE, chunk=50000, world=world, rank=r)
+
+            def step():
+                return sh.shade(sh.trace_finish(sh.trace_begin([cam])))
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) / steps * 1e3)
+        asm = min(render_emulated(world, [cam], sdf, nets, fn, tracer_factory, tile=SHARD_TILE)[2] for _ in range(2))
+        out["n%d" % world] = {"rank_step_ms": [round(x, 3) for x in ms], "max_rank_step_ms": max(ms), "mean_rank_step_ms": sum(ms) / world,
+                              "assemble_ms": asm, "factor": frame_ms / max(ms), "factor_with_assemble": frame_ms / (max(ms) + asm)}
     return out
 
 
@@ -428,7 +444,7 @@ def main():
         K, W2C = scenes.fixture_camera_matrices(a.res, a.res, yaw_deg=45.0 * v)
         cams.append(Camera(a.res, a.res, K.to(dev), W2C.to(dev)))
     all_cams, cams = cams, cams[:n_views]
-    sharded = ShardedRenderer(sdf, nets, tracer, fn, tile=32, chunk=50000) if world > 1 else None
+    sharded = ShardedRenderer(sdf, nets, tracer, fn, tile=SHARD_TILE, chunk=50000) if world > 1 else None
 
     def step(stats=False):
         if world == 1:
@@ -577,7 +593,7 @@ def main():
             "config": {"workload": "C1: scene %s (seeded geometric-init SDF 8x256 + ggx material nets), %dx%d full image, "
                                    "sphere-trace + GGX shade, fp32%s" % (a.scene, a.res, a.res, " + hole filling + silhouette edge sampling" if a.edges else ""),
                        "views_per_step": n_views, "rays_per_step": rays,
-                       "sharding": "none (render_camera)" if world == 1 else "interleaved 32x32 tiles over %d ranks, RCCL gather" % world,
+                       "sharding": "none (render_camera)" if world == 1 else "interleaved %dx%d tiles over %d ranks, RCCL gather" % (SHARD_TILE, SHARD_TILE, world),
                        "tracer": {"sdf_threshold": 5e-5, "sphere_tracing_iters": 16, "n_steps": 128, "chunk": 50000}},
             "roofline": roof,
             "frame": {"E_reference_evals": E_alg, "E_source": "oracle (tests/golden/work_counts.json)" if E_oracle is not None else "device counters",

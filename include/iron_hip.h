@@ -395,6 +395,12 @@ int iron_shade_composite(const iron_shade_comp_nets* nets, float light, const fl
  * whose render_camera, models/raytracer.py:778-814, is one sequence). */
 int32_t iron_set_cu_limit(int32_t n_cus);
 
+/* Number of independent parts (1..4) the tracer cuts the rays of a call into, each part's kernel chain on its own stream (the
+ * caller's + library-owned side streams, forked / joined with events); results do not depend on it.  parts <= 0 restores the
+ * default (IRON_TRACE_SPLIT, else 1: measured no faster on MI355X, csrc/trace.hip).  Returns the previous setting.  Process-wide;
+ * no counterpart in the reference (RayTracer.forward, models/raytracer.py:45-103, is one sequence of masked torch ops). */
+int32_t iron_set_trace_split(int32_t parts);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): per-kernel device time from hipEvents recorded on the
  * caller's stream around each compute kernel.  Off by default.  iron_profile_read blocks on the

@@ -124,6 +124,7 @@ SYMBOLS = {
     "iron_trace_phase": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _I64, _P,
                                    _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "iron_set_cu_limit": (_I32, [_I32]),
+    "iron_set_trace_split": (_I32, [_I32]),
     "iron_profile_enable": (C.c_int, [_I32]),
     "iron_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
     "iron_shade_workspace_bytes": (_SZ, [_I64]),

@@ -14,11 +14,26 @@
 //   k_bisect_b the reference loops while ANY ray of the call is unfinished and updates ALL rays, so
 //              every ray runs the chunk-wide maximum count: finish the remaining iterations, then
 //              the final mid-point evaluation.
+//
+// Tails (an experiment kept behind IRON_TRACE_SPLIT = 2..4, default 1 = off): a persistent kernel ends on its slowest rays'
+// chains of dependent evaluations (up to 17 / 16 / 10 of ~90 us each) with part of the chip idle.  The split form cuts the
+// rays into independent parts whose kernel chains run on separate streams (the caller's + library-owned low-priority side
+// streams, forked and joined with events, so the call stays ordered on the caller's stream) so that one part's workgroups
+// could take the CUs another part's draining kernel frees.  Rays are independent and the chunk-global bisection count is an
+// atomicMax table shared by the parts, so the result does not depend on the split (tests/test_gpu_trace.py).  Measured on an
+// 80 k-ray tile shard (tools/shard_step_time.py, round 3): the two parts' kernels share the CUs evenly instead of one
+// filling in behind the other -- every kernel takes twice as long and the step 8.75 ms against 8.64 unsplit (unequal parts
+// 65/35/80 %: 9.1-9.3) -- stream priorities do not order workgroup dispatch between two resident persistent grids.
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
 #include "mlp_h2.h"
 #include "ggx_core.h"
 #include "h2_setup.h"
 
 namespace iron {
+
+constexpr int kMaxTraceSplits = 4;
 
 #ifndef IRON_FAST_SOFTPLUS
 #define IRON_FAST_SOFTPLUS 1
@@ -65,6 +80,7 @@ struct TraceArgs {
     float* points;
     float* sdf;
     float* dist;
+    int ray0;   // first ray of this part (rays [ray0, ray0 + n) are queued; ray ids stay global)
     int n;
     int n_steps;
     int iters;
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sphere(IRON_TRACE_KERNEL_AR
             if (base + nfree >= a.n) exhausted = true;
             const int rank = lane_rank(~act, j);
             if (!active && rank < avail) {
-                ray = base + rank;
+                ray = a.ray0 + base + rank;
                 const float ox = a.ray_o[3 * (size_t)ray], oy = a.ray_o[3 * (size_t)ray + 1], oz = a.ray_o[3 * (size_t)ray + 2];
                 dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
                 t = a.near[ray];
@@ -456,17 +472,25 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_b(IRON_TRACE_KERNEL_
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
 }
 
-__global__ void k_trace_stats(TraceWs w, int n_steps, iron_trace_stats* out) {
+// `w.cnt` = the first part's counters; the parts' counter blocks are kCntStride bytes apart
+constexpr size_t kCntStride = 256;
+__global__ void k_trace_stats(TraceWs w, int n_parts, int n_steps, iron_trace_stats* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        out->n_evals = w.cnt->n_evals;
-        out->n_sphere_conv = w.cnt->n_sphere_conv;
-        out->n_sampler = w.cnt->n_sampler;
-        out->n_bisect = w.cnt->n_root;
-        out->n_conv = w.cnt->n_sphere_conv + w.cnt->n_root;
-        long long e = w.cnt->n_evals_sphere + (long long)w.cnt->n_sampler * n_steps;
+        long long n_evals = 0, n_sphere_conv = 0, n_sampler = 0, n_root = 0, n_evals_sphere = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            const TraceCounters* c = (const TraceCounters*)((const char*)w.cnt + (size_t)p * kCntStride);
+            n_evals += c->n_evals; n_sphere_conv += c->n_sphere_conv; n_sampler += c->n_sampler; n_root += c->n_root;
+            n_evals_sphere += c->n_evals_sphere;
+        }
+        out->n_evals = n_evals;
+        out->n_sphere_conv = n_sphere_conv;
+        out->n_sampler = n_sampler;
+        out->n_bisect = n_root;
+        out->n_conv = n_sphere_conv + n_root;
+        long long e = n_evals_sphere + n_sampler * n_steps;
         for (int c = 0; c < w.n_chunks; ++c) e += (long long)w.chunk_roots[c] * (w.chunk_iters[c] + 1);
         out->n_evals_ref = e;
-        out->n_evals_sphere = w.cnt->n_evals_sphere;
+        out->n_evals_sphere = n_evals_sphere;
         out->reserved = 0;
     }
 }
@@ -484,7 +508,8 @@ static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
     L.n_chunks = (p && p->chunk > 0) ? (n + p->chunk - 1) / p->chunk : 1;
     if (L.n_chunks < 1) L.n_chunks = 1;
     size_t o = 0;
-    L.cnt = o; o += align256(sizeof(TraceCounters));
+    static_assert(sizeof(TraceCounters) <= kCntStride, "counter block");
+    L.cnt = o; o += kCntStride * kMaxTraceSplits;
     L.chunk_iters = o; o += align256(sizeof(int) * (size_t)L.n_chunks);
     L.chunk_roots = o; o += align256(sizeof(int) * (size_t)L.n_chunks);
     L.sampler_list = o; o += align256(sizeof(int) * nn);
@@ -552,6 +577,60 @@ extern "C" size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params*
     return ws_layout(n, p).total + align256(sizeof(int) * 65536);
 }
 
+// ---- side streams of the split form -------------------------------------------------------------------------------------
+namespace iron {
+namespace {
+struct SideStreams {
+    bool ready = false;
+    hipStream_t s[kMaxTraceSplits - 1];
+    hipEvent_t fork, join[kMaxTraceSplits - 1];
+};
+std::mutex g_side_mu;           // serialises the enqueue of split calls (streams and events are shared per device)
+SideStreams g_side[64];
+
+// IRON_TRACE_SPLIT = k (2..4) runs a call as k parts; unset / 0 / 1 = one part (the measured optimum, see the head of this file)
+std::atomic<int> g_trace_split{0};   // iron_set_trace_split; 0 = the environment's / default
+int trace_splits(int64_t n) {
+    static int from_env = -1;
+    if (from_env < 0) {
+        const char* e = getenv("IRON_TRACE_SPLIT");
+        from_env = e ? atoi(e) : 0;
+        if (from_env < 0) from_env = 0;
+    }
+    int k = g_trace_split.load(std::memory_order_relaxed);
+    if (k <= 0) k = from_env;
+    if (k < 1) k = 1;
+    if (k > kMaxTraceSplits) k = kMaxTraceSplits;
+    while (k > 1 && n < (int64_t)k * 256) --k;   // a part is at least two workgroup-passes of rays
+    return k;
+}
+
+int side_streams(SideStreams** out) {
+    int dev = 0;
+    IRON_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return IRON_ERR_UNSUPPORTED;
+    SideStreams& S = g_side[dev];
+    if (!S.ready) {
+        int least = 0, greatest = 0;
+        IRON_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        // lowest priority: a side part's workgroups take the CUs the caller-stream part leaves idle, not the other way round
+        for (int i = 0; i < kMaxTraceSplits - 1; ++i) {
+            IRON_HIP_TRY(hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, least));
+            IRON_HIP_TRY(hipEventCreateWithFlags(&S.join[i], hipEventDisableTiming));
+        }
+        IRON_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+        S.ready = true;
+    }
+    *out = &S;
+    return IRON_OK;
+}
+}  // namespace
+}  // namespace iron
+
+extern "C" int32_t iron_set_trace_split(int32_t parts) {
+    return g_trace_split.exchange(parts > 0 ? (parts > kMaxTraceSplits ? kMaxTraceSplits : parts) : 0, std::memory_order_relaxed);
+}
+
 extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps,
                                 const float* ray_o, const float* ray_d, const float* near, const float* far,
                                 const uint8_t* work, const int64_t* ray_index, int64_t n, int32_t* chunk_iters,
@@ -569,55 +648,88 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     if (chunk_iters && (n_chunks < 1 || n_chunks > 65536)) return IRON_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
-    TraceWs w;
-    w.cnt = (TraceCounters*)(base + L.cnt);
-    w.sampler_list = (int*)(base + L.sampler_list);
-    w.root_list = (int*)(base + L.root_list);
-    w.root_lo = (float*)(base + L.lo);
-    w.root_hi = (float*)(base + L.hi);
-    w.root_flo = (float*)(base + L.flo);
-    w.root_fhi = (float*)(base + L.fhi);
-    w.root_k = (int*)(base + L.k);
-    w.chunk_iters = chunk_iters ? chunk_iters : (int*)(base + L.chunk_iters);
-    w.chunk_roots = (int*)(base + L.chunk_roots);
-    w.n_chunks = (int)(chunk_iters ? n_chunks : L.n_chunks);
+    TraceWs w0;
+    w0.cnt = (TraceCounters*)(base + L.cnt);
+    w0.sampler_list = (int*)(base + L.sampler_list);
+    w0.root_list = (int*)(base + L.root_list);
+    w0.root_lo = (float*)(base + L.lo);
+    w0.root_hi = (float*)(base + L.hi);
+    w0.root_flo = (float*)(base + L.flo);
+    w0.root_fhi = (float*)(base + L.fhi);
+    w0.root_k = (int*)(base + L.k);
+    w0.chunk_iters = chunk_iters ? chunk_iters : (int*)(base + L.chunk_iters);
+    w0.chunk_roots = (int*)(base + L.chunk_roots);
+    w0.n_chunks = (int)(chunk_iters ? n_chunks : L.n_chunks);
     if (chunk_iters && n_chunks > L.n_chunks) {
         // multi-rank: the chunk table covers the whole image, not just this rank's rays
         if (workspace_bytes < L.total + align256(sizeof(int) * (size_t)n_chunks)) return IRON_ERR_WORKSPACE;
-        w.chunk_roots = (int*)(base + L.total);
+        w0.chunk_roots = (int*)(base + L.total);
     }
-    TraceArgs a;
-    a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.work = work; a.ray_index = ray_index;
-    a.lin = lin_steps; a.conv = conv; a.points = points; a.sdf = sdf_out; a.dist = dist;
-    a.n = (int)n; a.n_steps = p->n_steps; a.iters = p->sphere_tracing_iters; a.thr = p->sdf_threshold;
-    a.chunk = p->chunk > 0 ? p->chunk : 0;
+    TraceArgs a0;
+    a0.ray_o = ray_o; a0.ray_d = ray_d; a0.near = near; a0.far = far; a0.work = work; a0.ray_index = ray_index;
+    a0.lin = lin_steps; a0.conv = conv; a0.points = points; a0.sdf = sdf_out; a0.dist = dist;
+    a0.ray0 = 0; a0.n = (int)n; a0.n_steps = p->n_steps; a0.iters = p->sphere_tracing_iters; a0.thr = p->sdf_threshold;
+    a0.chunk = p->chunk > 0 ? p->chunk : 0;
     const bool h2 = h2_sdf_usable(sdf);
+
+    // the parts: rays [b_k, b_{k+1}), own counters, own stretch [b_k, ..) of every list (a part lists at most its own rays);
+    // both phases of a call see the same n, hence the same split
+    const int parts = trace_splits(n);
+    int64_t bnd[kMaxTraceSplits + 1];
+    for (int k = 0; k <= parts; ++k) bnd[k] = k == parts ? n : ((n * k / parts) + 31) / 32 * 32;
+    if (parts == 2) {   // experiment: IRON_TRACE_SPLIT_FRAC = percent of the rays in the caller-stream part
+        static int frac = -1;
+        if (frac < 0) { const char* e = getenv("IRON_TRACE_SPLIT_FRAC"); frac = e ? atoi(e) : 50; if (frac < 5 || frac > 95) frac = 50; }
+        bnd[1] = ((n * frac / 100) + 31) / 32 * 32;
+    }
+    SideStreams* S = nullptr;
+    std::unique_lock<std::mutex> lock(g_side_mu, std::defer_lock);
+    if (parts > 1) {
+        lock.lock();
+        const int rc = side_streams(&S);
+        if (rc != IRON_OK) return rc;
+    }
     if (phase == 0) {
-        IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, align256(sizeof(TraceCounters)), st));
+        IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, kCntStride * kMaxTraceSplits, st));
         if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));
         else IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int) * (size_t)L.n_chunks), st));
-        IRON_HIP_TRY(hipMemsetAsync(w.chunk_roots, 0, sizeof(int) * (size_t)w.n_chunks, st));
-        const int64_t tiles = (n + 31) / 32;
-        {
-            ProfScope ps(IRON_PROF_SPHERE, st);
-            launch_trace_kernel(0, h2, sdf, a, w, tiles, st);
-        }
-        {
-            ProfScope ps(IRON_PROF_SAMPLER, st);
-            launch_trace_kernel(1, h2, sdf, a, w, (n + kSamplerSlots - 1) / kSamplerSlots, st);
-        }
-        {
-            ProfScope ps(IRON_PROF_BISECT_A, st);
-            launch_trace_kernel(2, h2, sdf, a, w, tiles, st);
-        }
-    } else {
-        const int64_t tiles = (n + 31) / 32;
-        {
-            ProfScope ps(IRON_PROF_BISECT_B, st);
-            launch_trace_kernel(3, h2, sdf, a, w, tiles, st);
-        }
-        if (stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w, p->n_steps, stats);
+        IRON_HIP_TRY(hipMemsetAsync(w0.chunk_roots, 0, sizeof(int) * (size_t)w0.n_chunks, st));
     }
+    if (parts > 1) IRON_HIP_TRY(hipEventRecord(S->fork, st));
+    // side parts first: their launches are queued before the caller-stream part occupies the chip
+    for (int k = parts - 1; k >= 0; --k) {
+        hipStream_t sk = k == 0 ? st : S->s[k - 1];
+        if (k > 0) IRON_HIP_TRY(hipStreamWaitEvent(sk, S->fork, 0));
+        TraceWs w = w0;
+        TraceArgs a = a0;
+        const int64_t b0 = bnd[k], nk = bnd[k + 1] - bnd[k];
+        if (nk <= 0) continue;
+        w.cnt = (TraceCounters*)(base + L.cnt + (size_t)k * kCntStride);
+        w.sampler_list += b0; w.root_list += b0; w.root_lo += b0; w.root_hi += b0; w.root_flo += b0; w.root_fhi += b0; w.root_k += b0;
+        a.ray0 = (int)b0; a.n = (int)nk;
+        const int64_t tiles = (nk + 31) / 32;
+        if (phase == 0) {
+            {
+                ProfScope ps(IRON_PROF_SPHERE, sk);
+                launch_trace_kernel(0, h2, sdf, a, w, tiles, sk);
+            }
+            {
+                ProfScope ps(IRON_PROF_SAMPLER, sk);
+                launch_trace_kernel(1, h2, sdf, a, w, (nk + kSamplerSlots - 1) / kSamplerSlots, sk);
+            }
+            {
+                ProfScope ps(IRON_PROF_BISECT_A, sk);
+                launch_trace_kernel(2, h2, sdf, a, w, tiles, sk);
+            }
+        } else {
+            ProfScope ps(IRON_PROF_BISECT_B, sk);
+            launch_trace_kernel(3, h2, sdf, a, w, tiles, sk);
+        }
+        if (k > 0) IRON_HIP_TRY(hipEventRecord(S->join[k - 1], sk));
+    }
+    for (int k = 1; k < parts; ++k)   // join: everything behind this call on the caller's stream sees all parts finished
+        if (bnd[k + 1] > bnd[k]) IRON_HIP_TRY(hipStreamWaitEvent(st, S->join[k - 1], 0));
+    if (phase == 1 && stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w0, parts, p->n_steps, stats);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

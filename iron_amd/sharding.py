@@ -7,7 +7,9 @@ The reference has no distributed code; rays are independent, so the o
      and a chunk's rays live on several ranks, and
   2. one gather of the finished per-pixel buffers to rank 0, followed by a local un-tile permutation.
 Tiles are dealt round-robin (tile_id % world) because the cost per ray varies ~15x and is spatially
-coherent; weights (5.4 MB) are replicated.
+coherent; weights (5.4 MB) are replicated.  Default tile: 8x8 pixels -- rays are independent and every
+kernel works from ray lists, so nothing is gained from larger tiles, and at 800x800 over 8 ranks 32x32 tiles leave the
+slowest rank 8 % above the mean where 8x8 tiles leave 0.2 % (tools/shard_step_time.py).
 """
 from __future__ import annotations
 
@@ -162,7 +164,7 @@ class ShardedRenderer:
     `world` / `rank` override the process group's: shard emulation on one card (tests/test_gpu_shards.py, tools/
     shard_scaling.py drive the phase methods of `world` instances by hand and do the exchanges in memory)."""
 
-    def __init__(self, sdf_network, color_network_dict, raytracer, render_fn, tile: int = 32, chunk: int = 50000,
+    def __init__(self, sdf_network, color_network_dict, raytracer, render_fn, tile: int = 8, chunk: int = 50000,
                  group=None, world: Optional[int] = None, rank: Optional[int] = None):
         self.sdf_network = sdf_network
         self.nets = color_network_dict
@@ -304,7 +306,7 @@ class ShardedRenderer:
 
 
 @torch.no_grad()
-def render_emulated(world: int, cameras, sdf_network, color_network_dict, render_fn, raytracer_factory, tile: int = 32,
+def render_emulated(world: int, cameras, sdf_network, color_network_dict, render_fn, raytracer_factory, tile: int = 8,
                     chunk: int = 50000, fill_holes: bool = False, handle_edges: bool = False):
     """The sharded render of `world` ranks played through on ONE device: `world` ShardedRenderer instances run their phase
     methods one after the other and the exchanges (MAX of the chunk tables, all-gather, gather) are done in memory -- the

@@ -114,3 +114,37 @@ def test_chunk_semantics_and_direct_forward():
     e = torch.zeros(0, 3, device="cuda")
     out0 = RayTracer()(SDFHandle(sdf), e, e, e[:, 0], e[:, 0], torch.zeros(0, dtype=torch.bool, device="cuda"))
     assert out0["points"].shape == (0, 3)
+
+
+@torch.no_grad()
+def test_split_form_is_bit_equal():
+    """iron_set_trace_split: the rays of one call run as 2 / 3 / 4 independent parts on separate streams (own queues and lists, the
+    chunk-count table shared through atomicMax).  Rays are independent, so every output and every work counter must equal the
+    one-part run bit for bit -- with several bisection chunks straddling the part boundaries."""
+    from iron_amd import _lib
+    from iron_amd.raytracer import Camera, RayTracer, raytrace_pixels
+    import iron_amd.raytracer as RT
+    dev = torch.device("cuda", 0)
+    nets = {k: v.to(dev) for k, v in scenes.build_networks("S1").items()}
+    K, W2C = scenes.fixture_camera_matrices(160, 160)
+    cam = Camera(160, 160, K.to(dev), W2C.to(dev))
+    lib = _lib.load()
+    old = RT.VERBOSE_MODE
+    prev = lib.iron_set_trace_split(1)
+    try:
+        RT.VERBOSE_MODE = True
+        tr = RayTracer()
+        want = raytrace_pixels(nets["sdf_network"], tr, cam.get_uv(), cam, max_num_rays=3000)
+        want_stats = dict(tr.last_stats)
+        assert int(want["convergent_mask"].sum()) > 1000 and want_stats["n_bisect"] > 50
+        for parts in (2, 3, 4):
+            lib.iron_set_trace_split(parts)
+            tr2 = RayTracer()
+            got = raytrace_pixels(nets["sdf_network"], tr2, cam.get_uv(), cam, max_num_rays=3000)
+            torch.cuda.synchronize()
+            for k in ("convergent_mask", "points", "sdf", "distance", "depth"):
+                assert torch.equal(got[k], want[k]), (parts, k)
+            assert tr2.last_stats == want_stats, (parts, tr2.last_stats, want_stats)
+    finally:
+        RT.VERBOSE_MODE = old
+        lib.iron_set_trace_split(prev)

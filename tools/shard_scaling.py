@@ -35,7 +35,7 @@ def frame_ms(f, reps=3):
 
 def main():
     sizes = [int(x) for x in sys.argv[1:]] or [800, 1600]
-    tile = int(os.environ.get("IRON_SHARD_TILE", "32"))
+    tile = int(os.environ.get("IRON_SHARD_TILE", "8"))
     nets = {k: v.cuda() for k, v in scenes.build_networks("S0").items()}
     fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
     sdf = nets["sdf_network"]
