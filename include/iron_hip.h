@@ -96,9 +96,15 @@ int iron_net_destroy(iron_net_t* net);
 int iron_sdf_forward(const iron_net_t* sdf, const float* x, int64_t n, float* out, int32_t out_cols, void* stream);
 
 /* SDFNetwork.get_all(x, is_training=False) (models/fields.py:120-137): sdf [n], feature
- * [n,d_out-1], grad = d sdf/dx [n,3] (forward-mode, no autograd graph).  Any output may be NULL. */
+ * [n,d_out-1], grad = d sdf/dx [n,3] (closed form, no autograd graph).  Any output may be NULL.
+ * `workspace` (iron_sdf_get_all_workspace_bytes(sdf, n) bytes, 16-byte aligned, caller-owned, contents undefined afterwards) is
+ * the tape of the reverse-mode kernel: forward pass, then ONE reverse sweep over transposed weights (csrc/getall_rev.hip) -- what
+ * autograd.grad does in the reference.  The query returns 0 for a network that has no reverse stream (any shape other than the
+ * reference's 8 x 256 / skip 4 / PE-6 / 257 outputs, or IRON_GETALL=fwd); with workspace == NULL the gradient is evaluated as
+ * three forward-mode tangents instead (same results to rounding, 2.3x the matrix work). */
+size_t iron_sdf_get_all_workspace_bytes(const iron_net_t* sdf, int64_t n);
 int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sdf_out, float* feature,
-                     float* grad, void* stream);
+                     float* grad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* RenderingNetwork.forward (models/fields.py:203-239).  view_dirs may be NULL for modes that do
  * not read it.  out [n,d_out].

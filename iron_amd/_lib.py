@@ -90,7 +90,8 @@ SYMBOLS = {
     "iron_net_create": (C.c_int, [C.POINTER(_P), C.POINTER(iron_net_desc), C.POINTER(iron_linear), _P]),
     "iron_net_destroy": (C.c_int, [_P]),
     "iron_sdf_forward": (C.c_int, [_P, _P, _I64, _P, _I32, _P]),
-    "iron_sdf_get_all": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "iron_sdf_get_all_workspace_bytes": (_SZ, [_P, _I64]),
+    "iron_sdf_get_all": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _SZ, _P]),
     "iron_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "iron_camera_rays": (C.c_int, [C.POINTER(_F), C.POINTER(_F), _P, _I64, _P, _P, _P, _P]),
     "iron_intersect_sphere": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),

@@ -19,9 +19,9 @@ LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/i
 OBJ_DIR = os.path.join(CSRC, "build")
 MANIFEST = os.path.join(OBJ_DIR, "manifest.json")  # which flag set every translation unit was compiled with (bench.py echoes it)
 
-SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "w16.hip", "pointwise.hip", "trace.hip", "shade.hip", "nerf.hip", "neus.hip", "profile.hip"]
+SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "w16.hip", "pointwise.hip", "trace.hip", "shade.hip", "getall_rev.hip", "nerf.hip", "neus.hip", "profile.hip"]
 TRAIN_SOURCES = ["train.hip"]
-HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "gemm_h2.h", "lds_dma.h", "iron_common.h", "mlp_core.h", "mlp_h2.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
+HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "gemm_h2.h", "lds_dma.h", "iron_common.h", "mlp_core.h", "mlp_h2.h", "mlp_h2_rev.h", "shade_args.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
 
 BASE_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -37,6 +37,11 @@ BASE_FLAGS = [
 # behind this option has crashed hipcc 7.2 on some revisions of trace.hip; a source that fails with it is recompiled
 # with weaker flag sets (see compile_one; the kernels are correct either way, only slower).
 OPTIONAL_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+
+# per-source additions.  getall_rev.hip: its ring step carries a longer staged epilogue than mlp_h2.h's; with the default
+# -pragma-unroll-threshold (16 K) LLVM silently leaves the 16-k-step loop of step_hidden_x rolled (runtime stage dispatch, the
+# epilogue state in scratch: 19 630 scratch instructions instead of ~200)
+SOURCE_FLAGS = {"getall_rev.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc() -> str:
@@ -54,6 +59,7 @@ def _digest(extra_flags) -> str:
             with open(p, "rb") as f:
                 h.update(f.read())
     h.update(" ".join(BASE_FLAGS + OPTIONAL_FLAGS + list(extra_flags)).encode())
+    h.update(json.dumps(SOURCE_FLAGS, sort_keys=True).encode())
     return h.hexdigest()
 
 
@@ -89,9 +95,10 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
         attempts = [OPTIONAL_FLAGS, OPTIONAL_FLAGS + ["-DIRON_SAMPLER_DEFER=0"], []]
         r = None
         for i, opt in enumerate(attempts):
-            r = subprocess.run([hipcc] + BASE_FLAGS + opt + extra_flags + tail, capture_output=True, text=True)
+            per_src = SOURCE_FLAGS.get(src, [])
+            r = subprocess.run([hipcc] + BASE_FLAGS + opt + per_src + extra_flags + tail, capture_output=True, text=True)
             if r.returncode == 0:
-                used_flags[src] = {"flags": BASE_FLAGS + opt + extra_flags, "attempt": i, "fallback": i > 0}
+                used_flags[src] = {"flags": BASE_FLAGS + opt + per_src + extra_flags, "attempt": i, "fallback": i > 0}
                 break
             if verbose and i + 1 < len(attempts):
                 print("build: %s failed with [%s], retrying with [%s]" % (src, " ".join(opt), " ".join(attempts[i + 1])), file=sys.stderr)

@@ -109,7 +109,7 @@ struct H2StreamDev {
     uint32_t bias_off;    // f32 bias blocks [layer][8][2][16]
     uint32_t rows_off;    // f32 last-layer rows [3][8][2][16]
     uint32_t n_bias_layers;
-    uint32_t kind_mask[4]; // bit q: slot q of the sequence is a hidden (32 KiB) slot, else a head (8 KiB) slot
+    uint32_t kind_mask[4]; // bit q: slot q of the sequence is a hidden (32 KiB) slot, else a head (8 KiB) slot; slots >= 128 are hidden slots
 };
 
 }  // namespace iron
@@ -124,6 +124,8 @@ struct iron_net {
     void* h2_blob;        // h2 (split-fp16) stream, SDF nets
     iron::H2StreamDev h2_trace;  // hidden stack only
     iron::H2StreamDev h2_full;   // + the feature rows of the last layer
+    void* h2_rev_blob;    // stream of the reverse-mode get_all (getall_rev.hip): h2_full's slots + the transposed layers
+    iron::H2StreamDev h2_rev;
     void* h2_scratch;     // material nets with a skip layer on the h2 core: partial sums parked between layer 0 and the skip layer
     size_t h2_scratch_floats;
     void* w16_blob;       // stream of the 8-wave w16 core (w16.hip), SDF nets of the reference shape

@@ -183,6 +183,7 @@ struct Ring {
 #endif
     }
     __device__ __forceinline__ bool kind_of(int q) const {
+        if (q >= 128) return true;   // sequences longer than the mask (getall_rev.hip) end in hidden slots only
         const unsigned long long w = q < 64 ? mask_lo : mask_hi;
         return (w >> (q & 63)) & 1ull;
     }

@@ -517,6 +517,7 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
     if (rc != IRON_OK) {
         if (net->blob) (void)hipFree(net->blob);
         if (net->h2_blob) (void)hipFree(net->h2_blob);
+        if (net->h2_rev_blob) (void)hipFree(net->h2_rev_blob);
         if (net->h2_scratch) (void)hipFree(net->h2_scratch);
         if (net->w16_blob) (void)hipFree(net->w16_blob);
         delete net;
@@ -530,6 +531,7 @@ extern "C" int iron_net_destroy(iron_net_t* net) {
     if (!net) return IRON_OK;
     if (net->blob) IRON_HIP_TRY(hipFree(net->blob));
     if (net->h2_blob) IRON_HIP_TRY(hipFree(net->h2_blob));
+    if (net->h2_rev_blob) IRON_HIP_TRY(hipFree(net->h2_rev_blob));
     if (net->h2_scratch) IRON_HIP_TRY(hipFree(net->h2_scratch));
     if (net->w16_blob) IRON_HIP_TRY(hipFree(net->w16_blob));
     delete net;

@@ -59,6 +59,40 @@ __global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs h
     store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
 }
 
+// Transposed hidden slot (reverse-mode get_all, mlp_h2_rev.h): output row 32*to + i of the slot is ORIGINAL COLUMN col_off + row of the
+// layer, the k index runs over the layer's original rows (its output units, in the register order their sigma' * g tiles have):
+//   dst[ks][piece][lane = (i, h)][j] = W[o][col_off + 32 to + i] * scale[o] * mul,   o = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3)
+__global__ void k_pack_h2_hidden_T(_Float16* __restrict__ dst, PackSrc s, int to, int col_off, int cols_valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
+    if (e >= 16 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * to + i;
+    const int o = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+    float w = 0.0f;
+    if (row < cols_valid && o < s.rows_valid)
+        w = s.w[(size_t)(s.row_off + o) * s.ld + col_off + row] * s.scale[s.row_off + o] * s.mul;
+    store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
+}
+
+// Transposed PE rows: output row i of tile T lands in accumulator register r = (i&3) + 4 (i>>3) of lane-half hh = (i>>2)&1 and stands
+// for head slot 16 T + r in the role of the OTHER half -- the row of sin(2^k v_c) goes to the half whose head slot holds cos(2^k v_c)
+// and vice versa, so that each lane contracts its rows with the PE values it already has (getall_rev.hip: pe_contract).
+__global__ void k_pack_h2_pe_T(_Float16* __restrict__ dst, PackSrc s, int T, int col_off, int levels) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
+    if (e >= 16 * 64 * 8) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    const int r = (i & 3) + 4 * (i >> 3), hh = (i >> 2) & 1;
+    const int slot = 16 * T + r;
+    const int col = slot < 2 ? head_slot_column(slot, hh, levels) : (slot < head_slots(levels) ? head_slot_column(slot, 1 - hh, levels) : -1);
+    const int o = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+    float w = 0.0f;
+    if (col >= 0 && o < s.rows_valid)
+        w = s.w[(size_t)(s.row_off + o) * s.ld + col_off + col] * s.scale[s.row_off + o] * s.mul;
+    store_split(dst + ((size_t)(2 * ks) * 64 + lane) * 8 + j, dst + ((size_t)(2 * ks + 1) * 64 + lane) * 8 + j, w);
+}
+
 // head slot of a 4-component source (NeRF background points, mlp_core.h head_fill4): slot 0 = (x|y), 1 = (z|w), then
 // (sin|cos)(2^k v_c) at slot 2 + 4k + c; embedding columns: 4 raw, then per level [sin x4 | cos x4]
 __global__ void k_pack_h2_head4(_Float16* __restrict__ dst, PackSrc s, int levels, int col_off, int to, int slot_off) {
@@ -102,10 +136,16 @@ static int h2_overflow_check(iron_net* net) {
     return IRON_OK;
 }
 
-// Builds the h2 stream of an SDF network next to its fp32 pack.  Slot sequence (= memory order):
+// Builds the h2 streams of an SDF network next to its fp32 pack.  Slot sequence (= memory order):
 //   layer 0: 8 head slots; layers 1..n-2: per output tile [head slot if skip layer] hidden slot;
-//   then (full stream only) the 8 hidden slots of the feature rows of the last layer.
-int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st) {
+//   then (full stream only) the 8 hidden slots of the feature rows of the last layer;
+//   then (reverse stream only: the reference's 8 x 256 network with its feature rows) the transposed layers of the reverse sweep
+//   (mlp_h2_rev.h): for l = n-2 .. 1: 8 transposed hidden slots of W_l [+ 2 PE-row slots behind the skip layer's], then the 2
+//   PE-row slots of W_0.
+// The forward-only streams live in h2_blob (h2_trace / h2_full), the reverse stream is a second blob (h2_rev_blob) holding the
+// same forward slots followed by the transposed ones, so that one ring walks it end to end.
+static int pack_h2_sdf_blob(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, bool with_rev, void** blob_out,
+                            H2StreamDev* s_out, uint32_t* n_trace_out, uint32_t* n_full_out, hipStream_t st) {
     const iron_net_desc& d = net->desc;
     const int nl = d.n_linear;
     const int skip = d.skip_layer;
@@ -122,15 +162,25 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     if (has_feat) for (int to = 0; to < kHidTiles; ++to) add(1);
     const uint32_t n_full = (uint32_t)(table.size() / 2);
     if (n_full > 127) return IRON_ERR_UNSUPPORTED;
+    if (with_rev) {
+        for (int l = nl - 2; l >= 1; --l) {
+            for (int to = 0; to < kHidTiles; ++to) add(1);
+            if (l == skip) { add(1); add(1); }
+        }
+        add(1); add(1);
+    }
+    const uint32_t n_all = (uint32_t)(table.size() / 2);
+    if (n_all > 250) return IRON_ERR_UNSUPPORTED;
     const size_t data_bytes = off;
     const size_t table_off = (data_bytes + 255) & ~(size_t)255;
-    const size_t bias_off = table_off + 1024;
+    const size_t bias_off = table_off + 2048;
     const size_t rows_off = bias_off + kLdsBiasBytes;
     const size_t total = rows_off + kLdsRowsBytes + 65536;  // tail padding: the ring may prefetch past the end
-    IRON_HIP_TRY(hipMalloc(&net->h2_blob, total));
-    IRON_HIP_TRY(hipMemsetAsync(net->h2_blob, 0, total, st));
-    { const int rc0 = h2_overflow_reset(st); if (rc0 != IRON_OK) return rc0; }
-    char* base = (char*)net->h2_blob;
+    void* blob = nullptr;
+    IRON_HIP_TRY(hipMalloc(&blob, total));
+    *blob_out = blob;   // the caller owns it from here (freed with the net also when a later step fails)
+    IRON_HIP_TRY(hipMemsetAsync(blob, 0, total, st));
+    char* base = (char*)blob;
     IRON_HIP_TRY(hipMemcpyAsync(base + table_off, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     IRON_HIP_TRY(hipStreamSynchronize(st));  // `table` is host memory going out of scope
 
@@ -160,6 +210,22 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     if (has_feat)
         for (int to = 0; to < kHidTiles; ++to, ++q)
             hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), to, 0, kHidden);
+    if (with_rev) {
+        for (int l = nl - 2; l >= 1; --l) {
+            const bool is_skip = (l == skip);
+            const float mul = is_skip ? kInvSqrt2 : 1.0f;
+            const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul);
+            const int cols_valid = is_skip ? kHidden - pe : kHidden;   // the layer's inputs that come from the previous layer
+            for (int to = 0; to < kHidTiles; ++to, ++q)
+                hipLaunchKernelGGL(k_pack_h2_hidden_T, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, cols_valid);
+            if (is_skip)
+                for (int T = 0; T < 2; ++T, ++q)
+                    hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, T, kHidden - pe, d.multires);
+        }
+        const PackSrc p0 = make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f);
+        for (int T = 0; T < 2; ++T, ++q)
+            hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32), dim3(256), 0, st, slot_ptr(q), p0, T, 0, d.multires);
+    }
     // f32 side blocks: biases of layers 0..nl-2 (+ feature bias as block nl-1), last-layer row 0
     for (int l = 0; l <= nl - 2; ++l)
         hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, L[l].out_dim);
@@ -170,15 +236,40 @@ int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, c
     IRON_HIP_TRY(hipStreamSynchronize(st));
 
     H2StreamDev s;
-    s.base = base; s.table_off = (uint32_t)table_off; s.n_slots = n_trace; s.bias_off = (uint32_t)bias_off;
+    s.base = base; s.table_off = (uint32_t)table_off; s.n_slots = n_all; s.bias_off = (uint32_t)bias_off;
     s.rows_off = (uint32_t)rows_off; s.n_bias_layers = (uint32_t)nl;
     for (int i = 0; i < 4; ++i) s.kind_mask[i] = 0;
-    for (size_t k = 0; k < table.size() / 2; ++k)
+    for (size_t k = 0; k < table.size() / 2; ++k) {
+        if (k >= 128) { if (!table[2 * k + 1]) return IRON_ERR_UNSUPPORTED; continue; }   // beyond the mask: hidden slots only
         if (table[2 * k + 1]) s.kind_mask[k >> 5] |= 1u << (k & 31);
+    }
+    *s_out = s;
+    *n_trace_out = n_trace;
+    *n_full_out = n_full;
+    return IRON_OK;
+}
+
+int build_h2_sdf(iron_net* net, const iron_linear* L, const float* scale_base, const size_t* soff, hipStream_t st) {
+    const iron_net_desc& d = net->desc;
+    { const int rc0 = h2_overflow_reset(st); if (rc0 != IRON_OK) return rc0; }
+    H2StreamDev s;
+    uint32_t n_trace = 0, n_full = 0;
+    int rc = pack_h2_sdf_blob(net, L, scale_base, soff, false, &net->h2_blob, &s, &n_trace, &n_full, st);
+    if (rc != IRON_OK) return rc;
+    s.n_slots = n_trace;
     net->h2_trace = s;
     s.n_slots = n_full;
     net->h2_full = s;
-    return h2_overflow_check(net);
+    // the reverse stream: the network shape getall_rev.hip is written for (8 hidden layers of 256, skip at 4, PE-6, feature rows)
+    if (d.n_linear == 9 && d.skip_layer == 4 && d.multires == kSdfPeLevels && d.d_out == kHidden + 1) {
+        H2StreamDev r;
+        rc = pack_h2_sdf_blob(net, L, scale_base, soff, true, &net->h2_rev_blob, &r, &n_trace, &n_full, st);
+        if (rc != IRON_OK) return rc;
+        net->h2_rev = r;
+    }
+    rc = h2_overflow_check(net);
+    if (rc == IRON_OK && !net->h2_blob && net->h2_rev_blob) { (void)hipFree(net->h2_rev_blob); net->h2_rev_blob = nullptr; }
+    return rc;
 }
 
 // h2 stream of a material network.  Sequence (= memory order):

@@ -13,6 +13,7 @@
 #include "mlp_h2.h"
 #include "h2_setup.h"
 #include "ggx_core.h"
+#include "shade_args.h"
 
 namespace iron {
 
@@ -67,17 +68,6 @@ __device__ __forceinline__ f32x16 zero_tile() {
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
     return v;
 }
-
-struct GradArgs {
-    const float* x;        // [*,3] point source
-    const int* list;       // hit list (indices into x) or null = identity
-    const int* count_ptr;  // device count or null
-    int count;             // used when count_ptr == null
-    float* feat_packed;    // [tiles][8][16][64] or null
-    float* sdf_out;        // [count] (list order) or null
-    float* grad_out;       // [count,3] (list order) or null
-    float* feat_rows;      // [count,256] row-major or null
-};
 
 constexpr int kSBufFloats = kHidTiles * 16 * 64;  // one layer's sigma'(z) for 32 points: 32 KiB
 
@@ -858,7 +848,7 @@ __global__ void k_composite_shade(CompShadeArgs a) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct ShadeLayout {
-    size_t count, list, grad, kd, ks, rr, feat, total;
+    size_t count, list, grad, kd, ks, rr, feat, park, park_bytes, total;
 };
 static ShadeLayout shade_layout(int64_t n) {
     ShadeLayout L;
@@ -872,13 +862,21 @@ static ShadeLayout shade_layout(int64_t n) {
     L.ks = o; o += al256(sizeof(float) * 3 * nn);
     L.rr = o; o += al256(sizeof(float) * nn);
     L.feat = o; o += al256(sizeof(float) * kSBufFloats * tiles);
+    L.park = o; L.park_bytes = getall_rev_park_bytes(n); o += L.park_bytes;   // tape of the reverse-mode get_all (getall_rev.hip)
     L.total = o;
     return L;
 }
 
 static int cu_count() { return cu_budget(); }
 
-static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st) {
+// park / park_bytes: the tape of the reverse-mode kernel (getall_rev.hip), taken when the network has a reverse stream and the
+// caller provided the workspace; otherwise the forward-mode kernels below
+static int launch_sdf_grad(const iron_net* sdf, const GradArgs& a, int64_t max_tiles, hipStream_t st, void* park = nullptr,
+                           size_t park_bytes = 0) {
+    if (park && getall_rev_usable(sdf)) {
+        if ((a.feat_packed || a.feat_rows) && !sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
+        return launch_sdf_getall_rev(sdf, a, max_tiles, park, park_bytes, st);
+    }
     if (h2_sdf_usable(sdf)) {
         static bool attr2 = false;
         if (!attr2) {
@@ -978,8 +976,13 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
 
 using namespace iron;
 
+extern "C" size_t iron_sdf_get_all_workspace_bytes(const iron_net_t* sdf, int64_t n) {
+    if (!sdf || sdf->desc.kind != IRON_NET_SDF || n <= 0 || !getall_rev_usable(sdf)) return 0;
+    return getall_rev_park_bytes(n);
+}
+
 extern "C" int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n, float* sdf_out, float* feature,
-                                float* grad, void* stream) {
+                                float* grad, void* workspace, size_t workspace_bytes, void* stream) {
     if (!sdf || sdf->desc.kind != IRON_NET_SDF || n < 0 || (n > 0 && !x)) return IRON_ERR_BAD_ARG;
     if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
     if (feature && !sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
@@ -987,7 +990,7 @@ extern "C" int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n
     GradArgs a;
     a.x = x; a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n;
     a.feat_packed = nullptr; a.sdf_out = sdf_out; a.grad_out = grad; a.feat_rows = feature;
-    return launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+    return launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 extern "C" int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t n, const float* cam_origin3, int32_t max_step,
@@ -1089,7 +1092,7 @@ extern "C" int iron_shade_composite(const iron_shade_comp_nets* nets, float ligh
     GradArgs ga;
     ga.x = points; ga.list = list; ga.count_ptr = count; ga.count = 0;
     ga.feat_packed = feat; ga.sdf_out = nullptr; ga.grad_out = grad; ga.feat_rows = nullptr;
-    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st);
+    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st, base + L.park, L.park_bytes);
     if (rc != IRON_OK) return rc;
     MatArgs ma;
     ma.points = points; ma.normals = grad; ma.view = nullptr; ma.feat_rows = nullptr; ma.feat_packed = feat;
@@ -1159,7 +1162,7 @@ extern "C" int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t 
     GradArgs ga;
     ga.x = points; ga.list = list; ga.count_ptr = count; ga.count = 0;
     ga.feat_packed = feat; ga.sdf_out = nullptr; ga.grad_out = grad; ga.feat_rows = nullptr;
-    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st);
+    int rc = launch_sdf_grad(nets->sdf, ga, max_tiles, st, base + L.park, L.park_bytes);
     if (rc != IRON_OK) return rc;
 
     MatArgs ma;

@@ -238,8 +238,9 @@ class SDFNetwork(_HipNet):
         feat = torch.empty((n, self.d_out - 1), dtype=torch.float32, device=xx.device)
         grad = torch.empty((n, 3), dtype=torch.float32, device=xx.device)
         with torch.cuda.device(xx.device):
+            ws, ws_bytes = _get_all_workspace(net, n, xx.device)
             _lib.check(_lib.load().iron_sdf_get_all(net.handle, xx.data_ptr(), n, sdf.data_ptr(), feat.data_ptr(),
-                                                    grad.data_ptr(), _lib.stream_ptr(xx.device)))
+                                                    grad.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(xx.device)))
         return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])
 
     @torch.no_grad()
@@ -253,9 +254,19 @@ class SDFNetwork(_HipNet):
         sdf = torch.empty((n, 1), dtype=torch.float32, device=xx.device)
         grad = torch.empty((n, 3), dtype=torch.float32, device=xx.device)
         with torch.cuda.device(xx.device):
-            _lib.check(_lib.load().iron_sdf_get_all(self.hip_net().handle, xx.data_ptr(), n, sdf.data_ptr(), None,
-                                                    grad.data_ptr(), _lib.stream_ptr(xx.device)))
+            net = self.hip_net()
+            ws, ws_bytes = _get_all_workspace(net, n, xx.device)
+            _lib.check(_lib.load().iron_sdf_get_all(net.handle, xx.data_ptr(), n, sdf.data_ptr(), None,
+                                                    grad.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(xx.device)))
         return sdf.reshape(sh + [1]), grad.reshape(sh + [3])
+
+
+def _get_all_workspace(net, n, device):
+    """The tape of the reverse-mode get_all kernel (include/iron_hip.h: iron_sdf_get_all): (tensor or None, bytes)."""
+    nbytes = int(_lib.load().iron_sdf_get_all_workspace_bytes(net.handle, n))
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 # IDR-style material MLP (reference: models/fields.py:141-239)

@@ -116,7 +116,7 @@ def edges():
     print("G15 loss", loss.item(), "edge pixels", int(res["edge_mask"].sum()), "param tensors", n_params)
 
 
-if __name__ == "__main__" and not ({"--floor", "--c3", "--stable"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--floor", "--floor14", "--c3", "--stable"} & set(sys.argv)):
     if "--edges" in sys.argv:
         edges()
     else:
@@ -251,6 +251,46 @@ def c3(size: int = 512, with64: bool = True):
     np.savez_compressed(os.path.join(HERE, "g17_train_c3_S1_%d.npz" % size), **out)
 
 
+def floor_g14():
+    """Round 3: the reference's fp64 run of the G14 setting (same crop, same loss weights) and, per tensor, its own fp32-vs-fp64
+    gradient discrepancy -- the conditioning floor of G14.  (The GGX lobe makes d loss / d roughness at a highlight pixel move by
+    ~1e-2 per 5e-7 of normal direction: two fp32-accurate evaluations of the normal differ by more than G14's original flat
+    5e-4 bound on the roughness net's tensors.)"""
+    g14 = dict(np.load(os.path.join(HERE, "g14_train_S1_c32.npz")))
+    nets = {k: v.double() for k, v in MG.build_reference_networks("S1").items()}
+    cam512 = MG.fixture_camera(512, 512)
+    cam, _, _ = cam512.crop_region(32, 32, ul_corner=(240, 240))
+    cam = MG.Camera64(cam.W, cam.H, cam.K.double(), cam.W2C.double())
+    fn = MG.make_render_fn(nets, GGXColocatedRenderer(use_cuda=False), torch.float64)
+    res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=False, handle_edges=False, is_training=True)
+    wt = torch.from_numpy(g14["loss_weights"]).double()
+    loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
+    loss.backward()
+    out = {"loss": np.float64(loss.item()), "convergent_mask": npf(res["convergent_mask"]), "color": npf(res["color"]), "normal": npf(res["normal"])}
+    worst_n = worst_s = 0.0
+    for key, g in grads_of(nets).items():
+        idx = sample_idx(g.size)
+        out["gnorm:" + key] = np.float64(np.linalg.norm(g))
+        out["gsample:" + key] = g[idx]
+        n32, s32 = float(g14["gnorm:" + key]), g14["gsample:" + key]
+        en = abs(n32 - np.linalg.norm(g)) / max(np.linalg.norm(g), 1e-12)
+        es = float(np.abs(s32 - g[idx]).max() / max(np.abs(g[idx]).max(), 1e-12))
+        out["floor_n:" + key] = np.float64(en)
+        out["floor_s:" + key] = np.float64(es)
+        worst_n, worst_s = max(worst_n, en), max(worst_s, es)
+        print("%-50s floor_n %.2e floor_s %.2e" % (key, en, es))
+    np.savez_compressed(os.path.join(HERE, "g14_floor_fp64.npz"), **out)
+    meta_path = os.path.join(HERE, "meta.json")
+    meta = json.load(open(meta_path))
+    meta["g14_ref32_vs_ref64_worst_gnorm_err"] = worst_n
+    meta["g14_ref32_vs_ref64_worst_gsample_err"] = worst_s
+    meta["g14_mask_flips_32_64"] = int((out["convergent_mask"] != g14["convergent_mask"]).sum())
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print("G14 floor: ref32 vs ref64 worst gnorm err %.3e, worst sampled entry %.3e, mask flips %d" % (worst_n, worst_s, meta["g14_mask_flips_32_64"]))
+
+
+if __name__ == "__main__" and "--floor14" in sys.argv:
+    floor_g14()
 if __name__ == "__main__" and "--floor" in sys.argv:
     floor_g15()
 if __name__ == "__main__" and "--c3" in sys.argv:

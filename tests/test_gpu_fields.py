@@ -244,3 +244,49 @@ def test_get_all_refuses_a_non_leaf_input_and_moved_parameters():
         net.lin0.bias.add_(1e-3)                       # parameters moved between forward and backward
     with pytest.raises(RuntimeError):
         sdf.sum().backward()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("scene", ["S1", "S3"])
+def test_get_all_reverse_mode_vs_forward_mode_and_fp64(scene):
+    """iron_sdf_get_all with the tape workspace runs the reverse-mode kernel (forward + one reverse sweep over transposed weights,
+    csrc/getall_rev.hip); without it, the forward-mode kernel (value + three tangents).  Same function: sdf and features to 2e-6,
+    the gradient to 1e-5 of its scale, on ragged batch sizes (1 ... 5000: partial waves, partial workgroups, several passes per
+    workgroup) -- and both against an fp64 torch evaluation of models/fields.py:120-137 (autograd) on the same weights."""
+    import ctypes as C
+    from iron_amd import _lib
+    from oracle import iron_ref as R
+    nets = scenes.build_networks(scene)
+    net = nets["sdf_network"].cuda()
+    lib = _lib.load()
+    h = net.hip_net()
+    g = torch.Generator().manual_seed(11)
+    assert lib.iron_sdf_get_all_workspace_bytes(h.handle, 1000) > 0, "no reverse stream for the reference-shaped SDF network"
+    for n in (1, 33, 127, 129, 1000, 5000):
+        x = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+        outs = []
+        for rev in (True, False):
+            sdf = torch.full((n,), 7.0, device="cuda"); feat = torch.full((n, 256), 7.0, device="cuda"); grad = torch.full((n, 3), 7.0, device="cuda")
+            nbytes = lib.iron_sdf_get_all_workspace_bytes(h.handle, n) if rev else 0
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.iron_sdf_get_all(h.handle, x.data_ptr(), n, sdf.data_ptr(), feat.data_ptr(), grad.data_ptr(),
+                                            ws.data_ptr() if rev else None, nbytes, _lib.stream_ptr(x.device)))
+            torch.cuda.synchronize()
+            outs.append((sdf.cpu(), feat.cpu(), grad.cpu()))
+        (s_r, f_r, g_r), (s_f, f_f, g_f) = outs
+        gscale = float(g_f.abs().max())
+        assert float((s_r - s_f).abs().max()) <= 2e-6, n
+        assert float((f_r - f_f).abs().max()) <= 2e-6 * max(1.0, float(f_f.abs().max())), n
+        assert float((g_r - g_f).abs().max()) <= 1e-5 * max(1.0, gscale), (n, float((g_r - g_f).abs().max()), gscale)
+        if n == 5000:   # fp64 autograd of the same network (oracle restatement of fields.py:82-137)
+            from _util import cpu_sd
+            sd64 = {k: v.double() for k, v in cpu_sd(nets["sdf_network"]).items()}
+            x64 = x.cpu().double().requires_grad_(True)
+            with torch.enable_grad():
+                y = R.sdf_forward(sd64, R.SDFSpec(), x64)
+                (g64,) = torch.autograd.grad(y[:, 0].sum(), x64)
+            e_rev = float((g_r.double() - g64).norm() / g64.norm())
+            e_fwd = float((g_f.double() - g64).norm() / g64.norm())
+            print("   %s get_all gradient rel-L2 vs fp64 autograd: reverse-mode %.2e, forward-mode %.2e" % (scene, e_rev, e_fwd))
+            assert e_rev <= max(2e-6, 2.0 * e_fwd), (e_rev, e_fwd)
+            assert float((s_r.double() - y[:, 0].detach()).abs().max()) <= 2e-6

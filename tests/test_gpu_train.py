@@ -447,22 +447,26 @@ def test_g14_training_render_matches_reference_gradients():
     loss = (res["color"] * wt).sum() + 0.1 * (res["normal"] * wt).sum()
     assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
     loss.backward()
-    n, worst_n, worst_s = 0, 0.0, 0.0
+    # Against the reference's fp64 run of the same setting (g14_floor_fp64.npz, make_golden_train.py --floor14), per tensor within
+    # max(5e-4 | 2e-3, 1.5 x the reference's own fp32-vs-fp64 discrepancy).  The floor matters for two networks: d loss / d roughness
+    # at a highlight pixel moves by ~1e-2 per 5e-7 of normal direction (GGX: (1 - c^2) / alpha^2 with alpha ~ 1e-2), so the
+    # reference's fp32 run is itself 1.5e-3 ... 4.3e-3 off its fp64 run on the roughness net's tensors and 1.2e-4 on the specular
+    # albedo net's; everywhere else the floor is ~1e-7 and the flat bound applies.
+    f = golden("g14_floor_fp64.npz")
+    floor = lambda key: (float(f["floor_n:" + key]), float(f["floor_s:" + key]))
+    n, w, bad = _grads_vs_fp64_reference(nets, f, "gnorm:", "gsample:", floor, base_n=5e-4, base_s=2e-3)
+    # and for the record against the fp32 run (not asserted beyond a loose 2 x floor + 5e-4: two fp32-accurate normals differ)
+    worst32 = 0.0
     for name in NETS:
         for pname, p in nets[name].named_parameters():
             key = "%s/%s" % (name, pname)
-            assert p.grad is not None, key
             gr = p.grad.reshape(-1).double().cpu().numpy()
-            ref_n = float(g["gnorm:" + key])
-            en = abs(np.linalg.norm(gr) - ref_n) / max(ref_n, 1e-12)
-            ref_s = g["gsample:" + key]
-            idx = np.concatenate([np.arange(min(16, gr.size)), np.linspace(0, gr.size - 1, 32).astype(np.int64)])
-            es = float(np.abs(gr[idx] - ref_s).max() / max(np.abs(ref_s).max(), 1e-12))
-            worst_n, worst_s = max(worst_n, en), max(worst_s, es)
-            assert en <= 5e-4, (key, en)
-            assert es <= 2e-3, (key, es)
-            n += 1
-    print("G14: %d parameter tensors, worst |norm| error %.2e, worst sampled-entry error %.2e (of max)" % (n, worst_n, worst_s))
+            en32 = abs(np.linalg.norm(gr) - float(g["gnorm:" + key])) / max(float(g["gnorm:" + key]), 1e-12)
+            worst32 = max(worst32, en32)
+            assert en32 <= 5e-4 + 2.5 * floor(key)[0], (key, en32, floor(key)[0])
+    print("G14: %d parameter tensors vs ref64 worst |norm| %.2e entries %.2e (the reference's fp32 vs fp64: %.2e / %.2e); vs ref32 worst |norm| %.2e"
+          % (n, w["n"], w["s"], w["fn"], w["fs"], worst32))
+    assert not bad, bad
     assert n == golden_meta()["n_param_tensors_train_golden"]
     assert nets["point_light_network"].light.grad is not None
 
