@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
 #pragma unroll
             for (int to = 0; to < kHidTiles; ++to) {
                 const f32x16 o = h2_plain_tile(ring, fb, lane, to, true, X, pb);
-                if (want_feat) {
+                if (want_feat && !(IRON_REV_ABL & 4)) {
                     if (dst) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) dst[(to * 16 + r) * 64 + lane] = o[r];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
             float pe[kHeadSlots];
 #pragma unroll
             for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
-            head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
+            if (!(IRON_REV_ABL & 8)) head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
             const f32x16 g0 = h2_plain_tile(ring, bias, lane, 0, false, X, pb);      // W_4[:, 217:]^T d_4: the skip's PE rows
             pe_contract<0>(g0, pe, half, gx, gy, gz);
             const f32x16 g1 = h2_plain_tile(ring, bias, lane, 1, false, X, pb);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
             float pe[kHeadSlots];
 #pragma unroll
             for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
-            head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
+            if (!(IRON_REV_ABL & 8)) head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
             const f32x16 g0 = h2_plain_tile(ring, bias, lane, 0, false, X, pb);      // W_0^T d_0
             pe_contract<0>(g0, pe, half, gx, gy, gz);
             const f32x16 g1 = h2_plain_tile(ring, bias, lane, 1, false, X, pb);

@@ -31,7 +31,15 @@ struct ParkBuf {
 
 __device__ __forceinline__ int park_off(int layer, int tile, int wave) { return ((layer * kHidTiles + tile) * 4 + wave) * kParkTileBytes; }
 
+#ifndef IRON_REV_ABL
+#define IRON_REV_ABL 0   // timing ablations (garbage results): 1 no tape stores, 2 no tape loads, 4 no feature stores, 8 no PE recompute
+#endif
+
 __device__ __forceinline__ void park_store_piece(const ParkBuf& pb, int off, int piece, float a, float b, float c, float d) {
+#if IRON_REV_ABL & 1
+    asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d));
+    return;
+#endif
     u32x4 v;
     v[0] = __builtin_bit_cast(unsigned, a); v[1] = __builtin_bit_cast(unsigned, b);
     v[2] = __builtin_bit_cast(unsigned, c); v[3] = __builtin_bit_cast(unsigned, d);
@@ -45,6 +53,11 @@ __device__ __forceinline__ void park_store_tile(const ParkBuf& pb, int off, cons
 
 __device__ __forceinline__ f32x16 park_load_tile(const ParkBuf& pb, int off) {
     f32x16 p;
+#if IRON_REV_ABL & 2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { p[i] = 1.5f + (float)off; asm volatile("" : "+v"(p[i])); }
+    return p;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // (bit_cast of the builtin's result, as in mlp_core.h: assigning it to an ext_vector_type makes hipcc 7.2 load ONE dword and splat it)
