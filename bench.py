@@ -162,7 +162,7 @@ def _host_threads():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, 16))
+    return max(1, int(os.environ.get("IRON_CPU_THREADS", avail)))
 
 
 def _c2_cpu_baseline(threads):
@@ -292,13 +292,14 @@ def secondary_workload(a):
             sec = kernels["sdf_grad"]["ms_avg"] / 1e3
             ach = FLOP_SDF_GRAD * pts / sec
             traffic, traffic_src = _recorded_traffic("c2_sdf_grad")
-            roof = {"bound": "mfma", "kernel": "k_sdf_grad_h2 (get_all: value + analytic gradient + 256 features at 4096 x 128 points)",
+            roof = {"bound": "mfma", "kernel": "k_sdf_getall_rev_h2 (get_all: value + 256 features + reverse-mode gradient at 4096 x 128 points)",
                     "achieved": ach / 1e12, "peak": PEAK_F16_MFMA / 3.0 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_F16_MFMA / 3.0), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "flop_per_unit": FLOP_SDF_GRAD, "units_per_launch": pts, "avg_launch_ms": kernels["sdf_grad"]["ms_avg"],
                     "peak_basis": "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate MAC",
-                    "note": "algorithmic FLOP per point = 2 x (524 544 forward + 459 008 input-gradient) MAC (SURVEY 8d); the kernel evaluates the "
-                            "gradient as three forward-mode tangents (4 wave passes per point), which is not credited"}
+                    "note": "algorithmic FLOP per point = 2 x (524 544 forward + 459 008 input-gradient) MAC (SURVEY 8d); the kernel is a forward "
+                            "pass plus one reverse sweep over transposed weight slots (140 ring steps per 128 points), the sigma' tape of 8 KiB "
+                            "per point written to and read back from HBM (not algorithmic bytes: it is the tape autograd keeps in the reference)"}
         base.update({"metric": "krays/s stage-1 NeuS volume render (models/renderer.py), 4096 rays x 128 samples hierarchical",
                      "value": r["krays_per_s"], "unit": "krays/s", "ms_per_step": round(r["ms"] / a.steps, 3),
                      "config": {"workload": "C2: seeded networks of confs/womask_iron.conf (8x256 SDF, 8-layer PE-10 colour net, NeRF "
@@ -324,31 +325,42 @@ def secondary_workload(a):
 
 
 def cpu_baseline(scene: str, res: int):
-    """The oracle (torch-CPU port of the reference path) timed on this host on a bounded sample."""
+    """The oracle (torch-CPU port of the reference path) timed on this host's cores: config C0 -- the 64x64 crop,
+    ul = (224, 224), of the 512x512 fixture camera -- always, plus a bounded full view (`res` x `res`, default 160: ~5 s) of the same
+    scene, which is the figure `value` quotes because its ray mix (45.9 evaluations per ray, 46 % hits) is the frame's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import iron_ref as R
     from iron_amd import scenes
     from _util import oracle_scene
-    # the GPU box gives one job a 16-core share of a much larger host: size the pool to what we may use
+    # every core this job may use: the GPU box gives one job a share of a much larger host (sched_getaffinity), which is what
+    # os.cpu_count() alone would overstate; IRON_CPU_THREADS overrides
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))
+    threads = max(1, int(os.environ.get("IRON_CPU_THREADS", avail)))
     torch.set_num_threads(threads)
     print("[bench] cpu_baseline: oracle on %d threads (affinity %d, cpu_count %s)" % (threads, avail, os.cpu_count()),
           file=sys.stderr, flush=True)
     sc = oracle_scene(scenes.build_networks(scene))
+    K512, W2C512 = scenes.fixture_camera_matrices(512, 512)
+    c0 = R.CameraSpec(512, 512, K512, W2C512).crop(64, 64, (224, 224))
+    R.render_camera(sc, R.CameraSpec(16, 16, *scenes.fixture_camera_matrices(16, 16)))  # warm the thread pool
+    t0 = time.perf_counter()
+    R.render_camera(sc, c0)
+    dt0 = time.perf_counter() - t0
     K, W2C = scenes.fixture_camera_matrices(res, res)
     cam = R.CameraSpec(res, res, K, W2C)
-    R.render_camera(sc, R.CameraSpec(16, 16, *scenes.fixture_camera_matrices(16, 16)))  # warm the thread pool
     sc.counter.evals = 0
     t0 = time.perf_counter()
     out = R.render_camera(sc, cam)
     dt = time.perf_counter() - t0
     return {"value": res * res / dt / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%s %dx%d full view (fixture camera rescaled), trace+GGX shade, torch-CPU oracle, %.1f s" % (scene, res, res, dt),
-            "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean())}
+            "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean()),
+            "c0": {"value": 64 * 64 / dt0 / 1e6, "unit": "Mrays/s", "seconds": dt0,
+                   "sample": "BASELINE config C0: 64x64 crop, ul = (224, 224), of the 512x512 fixture camera (all rays hit: 8 evaluations per ray)"},
+            "host": {"affinity_cores": avail, "cpu_count": os.cpu_count()}}
 
 
 def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=6):

@@ -37,7 +37,8 @@ typedef enum iron_status {
     IRON_ERR_UNSUPPORTED = -2,  /* network shape / mode the kernels are not built for          */
     IRON_ERR_HIP = -3,          /* a HIP runtime call failed; see iron_last_hip_error()        */
     IRON_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                                    */
-    IRON_ERR_WORKSPACE = -5     /* workspace too small                                         */
+    IRON_ERR_WORKSPACE = -5,    /* workspace too small                                         */
+    IRON_ERR_RANGE = -6         /* IRON_H2_OVERFLOW=error: the previous call on this network left the fp16 range of the h2 core */
 } iron_status;
 
 int iron_version(void);
@@ -87,6 +88,17 @@ typedef struct iron_net_desc {
  * tensors may be freed afterwards).  Must be re-run when parameters change. */
 int iron_net_create(iron_net_t** out, const iron_net_desc* desc, const iron_linear* layers, void* stream);
 int iron_net_destroy(iron_net_t* net);
+
+/* Numeric envelope of the default ("h2", split-fp16) core: weights are checked at create (a network with a folded |w| >= 65 504
+ * runs on the exact-fp32 core); activations and features are guarded at run time: every entry that ran a network on the h2 core
+ * scans the values it returns, a non-finite one raises the network's flag, and the NEXT entry on that handle moves the network to
+ * the exact-fp32 MFMA core for good (IRON_H2_OVERFLOW=error: returns IRON_ERR_RANGE instead).  The reference is plain fp32
+ * (models/fields.py:82-98, 203-239), which the exact core reproduces over the whole fp32 range.
+ *   iron_net_numeric_status: synchronises `stream`; *status_out = bit 0: an overflow was seen, bit 1: the network runs on the exact
+ *                            core, bit 2: a flag is pending (the call just finished overflowed).
+ *   iron_net_force_exact:    on != 0 pins the network to the exact core; 0 returns it to the default core and clears the status. */
+int iron_net_numeric_status(const iron_net_t* net, int32_t* status_out, void* stream);
+int iron_net_force_exact(iron_net_t* net, int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched field queries

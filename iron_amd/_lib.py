@@ -124,6 +124,8 @@ SYMBOLS = {
                              _P, _SZ, _P]),
     "iron_trace_phase": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _I64, _P,
                                    _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "iron_net_numeric_status": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
+    "iron_net_force_exact": (C.c_int, [_P, _I32]),
     "iron_set_cu_limit": (_I32, [_I32]),
     "iron_set_trace_split": (_I32, [_I32]),
     "iron_profile_enable": (C.c_int, [_I32]),

@@ -19,7 +19,7 @@ LIB_TRAIN = os.path.join(CSRC, "libiron_train.so")  # backward passes (include/i
 OBJ_DIR = os.path.join(CSRC, "build")
 MANIFEST = os.path.join(OBJ_DIR, "manifest.json")  # which flag set every translation unit was compiled with (bench.py echoes it)
 
-SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "w16.hip", "pointwise.hip", "trace.hip", "shade.hip", "getall_rev.hip", "nerf.hip", "neus.hip", "profile.hip"]
+SOURCES = ["pack.hip", "pack_h2.hip", "sdf_forward.hip", "h2_kernels.hip", "w16.hip", "pointwise.hip", "trace.hip", "shade.hip", "getall_rev.hip", "envelope.hip", "nerf.hip", "neus.hip", "profile.hip"]
 TRAIN_SOURCES = ["train.hip"]
 HEADERS = [os.path.join("..", "..", "include", "iron_train.h"), "gemm_h2.h", "lds_dma.h", "iron_common.h", "mlp_core.h", "mlp_h2.h", "mlp_h2_rev.h", "shade_args.h", "h2_setup.h", "pack_common.h", "ggx_core.h", os.path.join("..", "..", "include", "iron_hip.h")]
 

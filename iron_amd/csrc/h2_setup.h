@@ -11,13 +11,13 @@ struct H2Meta {
     float b_last;
 };
 
-bool use_h2_core();
+bool use_h2_core();   // (also declared in iron_common.h)
 
 // The SDF stack on the h2 core (sdf_hidden_stack_h2) is written for the reference's 8 x 256 network with the skip at
 // layer 4 (models/network_conf.py:31-44) and needs the h2 stream (absent when a folded weight overflows fp16); any
 // other SDF network runs on the exact-fp32 core.
 inline bool h2_sdf_usable(const iron_net* net) {
-    return use_h2_core() && net->h2_blob && net->sdf.n_hidden_layers == 8 && net->sdf.skip_layer == 4;
+    return h2_enabled(net) && net->sdf.n_hidden_layers == 8 && net->sdf.skip_layer == 4;
 }
 
 // biases / output rows -> LDS, then start the weight ring.  Called once per kernel by all 256 threads.

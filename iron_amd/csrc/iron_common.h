@@ -131,6 +131,12 @@ struct iron_net {
     void* w16_blob;       // stream of the 8-wave w16 core (w16.hip), SDF nets of the reference shape
     iron::H2StreamDev w16_trace;
     int device;
+    // numeric envelope of the h2 core (envelope.hip): a flag word in pinned host memory the device writes through, and the
+    // sticky status it leads to -- the one mutable part of a handle
+    int* flag_host;
+    int* flag_dev;
+    int overflow_seen;    // a call on the h2 core returned non-finite values
+    int h2_disabled;      // the network runs on the exact-fp32 core from now on (iron_net_force_exact, or after an overflow)
 };
 
 namespace iron {
@@ -142,6 +148,13 @@ inline int hip_fail(hipError_t e) {
 }  // namespace iron
 
 namespace iron {
+bool use_h2_core();
+// may this network run on the h2 core at all?  (IRON_MLP_CORE, an h2 stream exists, no envelope overflow / force_exact)
+inline bool h2_enabled(const iron_net* net) { return use_h2_core() && net->h2_blob && !net->h2_disabled; }
+int envelope_create(iron_net* net);
+void envelope_destroy(iron_net* net);
+int envelope_begin(const iron_net* net);   // at the start of an entry point: acts on a flag raised by an earlier call
+void envelope_scan(const iron_net* net, const float* p, int64_t n_rows, const int* count_ptr, int width, hipStream_t st);
 int cu_total();    // CUs of the current device
 int cu_budget();   // CUs the launches of this moment may fill (iron_set_cu_limit; profile.hip)
 // hipEvent pair around one kernel launch when profiling is enabled (profile.hip)

@@ -33,6 +33,9 @@
 #ifndef IRON_H2_RING_AHEAD
 #define IRON_H2_RING_AHEAD 3
 #endif
+#ifndef IRON_H2_ROT_ISSUE
+#define IRON_H2_ROT_ISSUE 0    // experiment: ONE wave (in rotation) issues all 32 LDS-DMA pieces of a slot instead of 8 per wave
+#endif
 
 namespace iron {
 
@@ -151,6 +154,7 @@ struct RingSrc {
     __amdgpu_buffer_rsrc_t rsrc;
     const char* gbase;
     uint32_t off;
+    int turn;           // IRON_H2_ROT_ISSUE: the wave that issues this refill
 };
 
 struct RingStep {
@@ -174,6 +178,7 @@ struct Ring {
     int wave, lane;
     unsigned long long* stamps;  // diagnostic (IRON_H2_STAMP)
     int n_step;
+    int n_issue, n_sync;         // IRON_H2_ROT_ISSUE: refills issued / slots consumed so far
 
     __device__ __forceinline__ unsigned long long* cur_rec() const {
 #if IRON_H2_STAMP
@@ -196,6 +201,12 @@ struct Ring {
         s.src.rsrc = rsrc;
         s.src.gbase = gbase;
         s.src.off = off_issue;
+#if IRON_H2_ROT_ISSUE
+        s.src.turn = n_issue & 3;
+        ++n_issue;
+#else
+        s.src.turn = 0;
+#endif
         // The ring position is compile-time periodic after unrolling; hide that, or hipcc folds it into per-read
         // absolute LDS addresses (> 16-bit immediates: one v_add per ds_read, plus AGPR parking of the CSE'd sums).
         // As an opaque scalar the slot base is ONE v_add per step and every fragment read uses an immediate offset.
@@ -211,7 +222,11 @@ struct Ring {
     }
     __device__ __forceinline__ void sync() {
         h2_stamp(cur_rec(), 5);  // arrival at the step boundary
-#if IRON_H2_RING_AHEAD == 3
+#if IRON_H2_ROT_ISSUE
+        // the slot about to be consumed was issued whole by wave (n_sync & 3), which has issued nothing since
+        if ((n_sync & 3) == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ++n_sync;
+#elif IRON_H2_RING_AHEAD == 3
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #elif IRON_H2_RING_AHEAD == 2
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -239,6 +254,24 @@ __device__ __forceinline__ void dma_issue(const RingSrc& src, char* __restrict__
     return;
 #endif
     const int lane = threadIdx.x & 63;
+#if IRON_H2_ROT_ISSUE
+    if (src.turn != wave) return;
+    {
+        const char* gsrc = src.gbase + src.off + (hidden ? lane * 16 : lane * 4);
+        if (hidden) {
+#pragma unroll
+            for (int f = 0; f < 4 * kLoadsPerSlot; ++f)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 1024),
+                                                 (__attribute__((address_space(3))) void*)(wr + f * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4 * kLoadsPerSlot; ++f)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + f * 256),
+                                                 (__attribute__((address_space(3))) void*)(wr + f * 256), 4, 0, 0);
+        }
+    }
+    return;
+#endif
 #if IRON_H2_ASM_DMA
     // uniform base in SGPRs + a constant per-lane offset (lds_dma.h): no vector instruction per piece
     // running scalar pointers, opaque to the optimiser: hoisted out of the unrolled evaluation as loop invariants, the 16 piece
@@ -298,6 +331,7 @@ __device__ __forceinline__ void ring_start(Ring& r, const H2StreamDev& s, char* 
     r.mask_hi = (unsigned long long)s.kind_mask[2] | ((unsigned long long)s.kind_mask[3] << 32);
     r.q_issue = 0; r.off_issue = 0; r.b_issue = 0; r.b_take = 0; r.wave = wave; r.lane = lane;
     r.n_step = -kRingAhead;  // the start-up steps below are not ring steps
+    r.n_issue = 0; r.n_sync = 0;
 #if IRON_H2_STAMP
     r.stamps = blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(lds_base + kLdsStamp) + wave * kStampSteps * 8 : nullptr;
 #else
@@ -368,6 +402,17 @@ __device__ __forceinline__ f16x2 cvt_pk_rn(float x0, float x1) {
 // max(x, 0) as one v_med3_f32 (fmaxf would add a canonicalising v_max x, x, x in IEEE mode)
 __device__ __forceinline__ float relu_med3(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
 
+// relu that keeps a NaN a NaN (of either sign): 0.5 * (z + |z|), exact for every finite z.  v_med3_f32 / v_max_f32 return the OTHER
+// operand for a NaN input, so a hidden pre-activation that became inf - inf after an fp16 overflow (envelope.hip) would turn into a
+// plausible 0; this way it reaches the output and raises the flag.  (-inf gives NaN as well: it only arises behind an overflow.)
+__device__ __forceinline__ float relu_twice(float z) { return z + __builtin_fabsf(z); }
+__device__ __forceinline__ float relu_halve(float t) { return 0.5f * t; }
+__device__ __forceinline__ f32x16 relu_tile_nan(f32x16 z) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = relu_halve(relu_twice(z[i]));
+    return z;
+}
+
 // x - f32(h) with the fp16 operand read in place (low / high half of a packed pair): v_fma_mix_f32, exact
 __device__ __forceinline__ float residual_lo(unsigned hpair, float x) {
     float r;
@@ -423,8 +468,9 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
         if (ks == 6) { _Pragma("unroll") for (int i = 8 + a8; i < 8 + b8; ++i) { st.e[i] = __builtin_amdgcn_logf(st.e[i]); pin1(st.e[i]); } }
         if (ks == 7) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
         if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = __builtin_fmaf(st.e[i], kC2, st.z[i]); pin1(st.z[i]); } }
-    } else if constexpr (ACT == 1) {
-        if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
+    } else if constexpr (ACT == 1) {   // relu, NaN-preserving (relu_twice / relu_halve): two stages of one op per element
+        if (ks == 7) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.e[i] = relu_twice(st.z[i]); pin1(st.e[i]); } }
+        if (ks == 8) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = relu_halve(st.e[i]); pin1(st.z[i]); } }
     }   // ACT == 2: identity (a linear layer)
     if constexpr (EPI == 1) {
         if (ks == 9) {
@@ -599,8 +645,8 @@ __device__ __forceinline__ void h2_hidden_layer(Ring& ring, const char* bias, co
         if constexpr (LAST) hf[NT - 1] = softplus_tile<FAST>(h2_combine(acc[1][0], acc[1][1]));
         else h2_epilogue_split<FAST>(acc[1][0], acc[1][1], out[NT - 1]);
     } else if constexpr (ACT == 1) {
-        if constexpr (LAST) hf[NT - 1] = relu_tile(h2_combine(acc[1][0], acc[1][1]));
-        else split_tile(relu_tile(h2_combine(acc[1][0], acc[1][1])), out[NT - 1]);
+        if constexpr (LAST) hf[NT - 1] = relu_tile_nan(h2_combine(acc[1][0], acc[1][1]));
+        else split_tile(relu_tile_nan(h2_combine(acc[1][0], acc[1][1])), out[NT - 1]);
     } else {
         if constexpr (LAST) hf[NT - 1] = h2_combine(acc[1][0], acc[1][1]);
         else split_tile(h2_combine(acc[1][0], acc[1][1]), out[NT - 1]);

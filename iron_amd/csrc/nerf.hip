@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_nerf_h2(H2StreamDev hs, NerfNetDev n
             ring.sync();
             const RingStep s1 = ring.step();
             step_head(s1.rd, bias, s1.wr, s1.src, s1.hidden, wave, lane, to, false, hd2, a_hi, a_lo);
-            split_tile(relu_tile(h2_combine(a_hi, a_lo)), X[to]);
+            split_tile(relu_tile_nan(h2_combine(a_hi, a_lo)), X[to]);
         }
         f32x16 c_hi, c_lo;
         h2_hidden_layer<true, 0, false, 1, false, true>(ring, bias + 1 * 1024, hd, lane, X, Y, hf, c_hi, c_lo);
@@ -205,7 +205,8 @@ extern "C" int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, cons
     const int64_t waves = (int64_t)cus * 4;
     const unsigned grid = (unsigned)(tiles < waves ? tiles : waves);
     hipStream_t st = (hipStream_t)stream;
-    if (use_h2_core() && nerf->h2_blob && r.levels == 10 && r.levels_view == 4 && r.n_layers == 8 && r.skip_after == 4) {
+    { const int rce = envelope_begin(nerf); if (rce != IRON_OK) return rce; }
+    if (h2_enabled(nerf) && r.levels == 10 && r.levels_view == 4 && r.n_layers == 8 && r.skip_after == 4) {
         static bool attr = false;
         if (!attr) {
             IRON_HIP_TRY(hipFuncSetAttribute((const void*)k_nerf_h2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsNerfTotal));
@@ -215,6 +216,8 @@ extern "C" int iron_nerf_forward(const iron_net_t* nerf, const float* pts4, cons
         hipLaunchKernelGGL(k_nerf_h2, dim3((unsigned)(groups < cus ? groups : cus)), dim3(256), kLdsNerfTotal, st, nerf->h2_trace, r, pts4,
                            view_dirs, (int)n, alpha, rgb);
         IRON_HIP_TRY(hipGetLastError());
+        envelope_scan(nerf, alpha, n, nullptr, 1, st);
+        envelope_scan(nerf, rgb, n, nullptr, 3, st);
         return IRON_OK;
     }
     if (r.levels == 10 && r.levels_view == 4) {  // confs/womask_iron.conf: model.nerf

@@ -145,6 +145,8 @@ extern "C" const char* iron_strerror(int status) {
         case IRON_ERR_HIP: return "HIP runtime error (see iron_last_hip_error)";
         case IRON_ERR_NO_DEVICE: return "no gfx950 device visible";
         case IRON_ERR_WORKSPACE: return "workspace too small";
+        case IRON_ERR_RANGE: return "an activation or feature left the fp16 range of the h2 core (|x| >= 65504 or non-finite): results of the "
+                                    "previous call on this network were non-finite; use iron_net_force_exact / IRON_MLP_CORE=f32";
         default: return "unknown iron status";
     }
 }
@@ -514,10 +516,12 @@ extern "C" int iron_net_create(iron_net_t** out, const iron_net_desc* desc, cons
     else if (desc->kind == IRON_NET_RENDER) rc = create_render(net, layers, st);
     else if (desc->kind == IRON_NET_NERF) rc = create_nerf(net, layers, st);
     else rc = IRON_ERR_UNSUPPORTED;
+    if (rc == IRON_OK && net->h2_blob) rc = envelope_create(net);
     if (rc != IRON_OK) {
         if (net->blob) (void)hipFree(net->blob);
         if (net->h2_blob) (void)hipFree(net->h2_blob);
         if (net->h2_rev_blob) (void)hipFree(net->h2_rev_blob);
+        envelope_destroy(net);
         if (net->h2_scratch) (void)hipFree(net->h2_scratch);
         if (net->w16_blob) (void)hipFree(net->w16_blob);
         delete net;
@@ -532,6 +536,7 @@ extern "C" int iron_net_destroy(iron_net_t* net) {
     if (net->blob) IRON_HIP_TRY(hipFree(net->blob));
     if (net->h2_blob) IRON_HIP_TRY(hipFree(net->h2_blob));
     if (net->h2_rev_blob) IRON_HIP_TRY(hipFree(net->h2_rev_blob));
+    envelope_destroy(net);
     if (net->h2_scratch) IRON_HIP_TRY(hipFree(net->h2_scratch));
     if (net->w16_blob) IRON_HIP_TRY(hipFree(net->w16_blob));
     delete net;

@@ -83,9 +83,14 @@ extern "C" int iron_sdf_forward(const iron_net_t* net, const float* x, int64_t n
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_tiles = (n + kTile - 1) / kTile;
     if (((uintptr_t)x & 3) || ((uintptr_t)out & 3)) return IRON_ERR_BAD_ARG;
+    { const int rce = envelope_begin(net); if (rce != IRON_OK) return rce; }
     ProfScope ps(IRON_PROF_SDF_FORWARD, st);
-    if (out_cols == 1 && use_w16_core() && net->w16_blob) return launch_sdf_values_w16(net, x, n, out, st);
-    if (out_cols == 1 && h2_sdf_usable(net)) return launch_sdf_values_h2(net, x, n, out, st);
+    if (out_cols == 1 && use_w16_core() && net->w16_blob && !net->h2_disabled) return launch_sdf_values_w16(net, x, n, out, st);
+    if (out_cols == 1 && h2_sdf_usable(net)) {
+        const int rc = launch_sdf_values_h2(net, x, n, out, st);
+        envelope_scan(net, out, n, nullptr, 1, st);
+        return rc;
+    }
     if (out_cols == 1) {
         hipLaunchKernelGGL(k_sdf_values, dim3(grid_for_tiles(n_tiles)), dim3(64), 0, st, net->sdf, x, n, out, 1);
     } else {

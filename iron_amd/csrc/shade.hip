@@ -918,7 +918,7 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
     const int lp = d.multires > 0 ? d.multires : 0;
     const int lv = d.multires_view > 0 ? d.multires_view : 0;
     ProfScope ps(IRON_PROF_MATERIAL, st);
-    if (use_h2_core() && net->h2_blob && net->h2_scratch && r.skip_layer == 4 && r.n_hidden_layers == 8 && d.mode == IRON_MODE_IDR &&
+    if (h2_enabled(net) && net->h2_scratch && r.skip_layer == 4 && r.n_hidden_layers == 8 && d.mode == IRON_MODE_IDR &&
         lp == 10 && lv == 4) {   // the stage-1 colour net (confs/womask_iron.conf)
         static bool attr4 = false;
         if (!attr4) {
@@ -933,7 +933,7 @@ static int launch_material(const iron_net* net, const MatArgs& a, int64_t max_ti
         IRON_HIP_TRY(hipGetLastError());
         return IRON_OK;
     }
-    if (use_h2_core() && net->h2_blob && r.skip_layer == -1 && r.n_hidden_layers >= 2 && r.n_hidden_layers % 2 == 0) {
+    if (h2_enabled(net) && r.skip_layer == -1 && r.n_hidden_layers >= 2 && r.n_hidden_layers % 2 == 0) {
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)k_material_h2<0, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
@@ -987,10 +987,16 @@ extern "C" int iron_sdf_get_all(const iron_net_t* sdf, const float* x, int64_t n
     if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
     if (feature && !sdf->sdf.w_feat) return IRON_ERR_UNSUPPORTED;
     if (n == 0) return IRON_OK;
+    { const int rce = envelope_begin(sdf); if (rce != IRON_OK) return rce; }
     GradArgs a;
     a.x = x; a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n;
     a.feat_packed = nullptr; a.sdf_out = sdf_out; a.grad_out = grad; a.feat_rows = feature;
-    return launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream, workspace, workspace_bytes);
+    const int rc = launch_sdf_grad(sdf, a, (n + kTile - 1) / kTile, (hipStream_t)stream, workspace, workspace_bytes);
+    // the envelope guard (envelope.hip): sdf and gradient carry every hidden activation's overflow; the feature rows are guarded where
+    // they are split (the material networks' outputs)
+    envelope_scan(sdf, sdf_out, n, nullptr, 1, (hipStream_t)stream);
+    envelope_scan(sdf, grad, n, nullptr, 3, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t n, const float* cam_origin3, int32_t max_step,
@@ -999,6 +1005,7 @@ extern "C" int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t
     if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
     if (n == 0) return IRON_OK;
     if (!start || !points || !found) return IRON_ERR_BAD_ARG;
+    { const int rce = envelope_begin(sdf); if (rce != IRON_OK) return rce; }
     if (!h2_sdf_usable(sdf)) return IRON_ERR_UNSUPPORTED;  // the caller then walks with iron_sdf_get_all launches
     hipStream_t st = (hipStream_t)stream;
     static bool attr = false;
@@ -1016,6 +1023,7 @@ extern "C" int iron_edge_walk(const iron_net_t* sdf, const float* start, int64_t
     ProfScope ps(IRON_PROF_SDF_GRAD, st);
     hipLaunchKernelGGL(k_edge_walk_h2, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), kLdsGradTotal + 512, st, sdf->h2_trace, m, a);
     IRON_HIP_TRY(hipGetLastError());
+    envelope_scan(sdf, points, n, nullptr, 3, st);
     return IRON_OK;
 }
 
@@ -1029,11 +1037,14 @@ extern "C" int iron_render_forward(const iron_net_t* net, const float* points, c
     const int mode = net->desc.mode;
     if ((mode == IRON_MODE_IDR || mode == IRON_MODE_NO_VIEW_DIR) && !normals) return IRON_ERR_BAD_ARG;
     if ((mode == IRON_MODE_IDR || mode == IRON_MODE_NO_NORMAL) && !view_dirs) return IRON_ERR_BAD_ARG;
+    { const int rce = envelope_begin(net); if (rce != IRON_OK) return rce; }
     MatArgs a;
     a.points = points; a.normals = normals; a.view = view_dirs; a.feat_rows = features; a.feat_packed = nullptr;
     a.list = nullptr; a.count_ptr = nullptr; a.count = (int)n; a.normalise = 0; a.neg_normal_view = 0;
     a.list_order_aux = 1; a.out = out;
-    return launch_material(net, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+    const int rc = launch_material(net, a, (n + kTile - 1) / kTile, (hipStream_t)stream);
+    envelope_scan(net, out, n, nullptr, net->desc.d_out, (hipStream_t)stream);
+    return rc;
 }
 
 // composite: the GGX layout followed by the five extra scalar maps
@@ -1063,6 +1074,7 @@ extern "C" int iron_shade_composite(const iron_shade_comp_nets* nets, float ligh
     if (n < 0 || n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
     if (n == 0) return IRON_OK;
     if (!tab_trans || !tab_diff_trans || !ray_o || !ray_d || !points || !conv || !workspace) return IRON_ERR_BAD_ARG;
+    { int rce = envelope_begin(nets->sdf); for (int i = 0; i < 8 && rce == IRON_OK; ++i) rce = envelope_begin(mats[i]); if (rce != IRON_OK) return rce; }
     const ShadeLayout L = shade_layout(n);
     if (workspace_bytes < comp_extra_off(n, 5)) return IRON_ERR_WORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
@@ -1097,11 +1109,13 @@ extern "C" int iron_shade_composite(const iron_shade_comp_nets* nets, float ligh
     MatArgs ma;
     ma.points = points; ma.normals = grad; ma.view = nullptr; ma.feat_rows = nullptr; ma.feat_packed = feat;
     ma.list = list; ma.count_ptr = count; ma.count = 0; ma.normalise = 1; ma.list_order_aux = 1;
+    envelope_scan(nets->sdf, grad, n, count, 3, st);
     for (int i = 0; i < 8; ++i) {
         ma.neg_normal_view = (i == 0) ? 1 : 0;  // the diffuse head sees view := -normal (rendering_func.py:22)
         ma.out = raw[i];
         rc = launch_material(mats[i], ma, max_tiles, st);
         if (rc != IRON_OK) return rc;
+        envelope_scan(mats[i], raw[i], n, count, mats[i]->desc.d_out, st);
     }
     CompShadeArgs sa;
     sa.list = list; sa.count_ptr = count; sa.ray_o = ray_o; sa.ray_d = ray_d; sa.points = points; sa.grad = grad;
@@ -1134,6 +1148,13 @@ extern "C" int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t 
     if (n < 0 || n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
     if (n == 0) return IRON_OK;
     if (!tab_trans || !tab_diff_trans || !ray_o || !ray_d || !points || !conv || !workspace) return IRON_ERR_BAD_ARG;
+    {
+        int rce = envelope_begin(nets->sdf);
+        if (rce == IRON_OK) rce = envelope_begin(nets->diffuse_albedo);
+        if (rce == IRON_OK) rce = envelope_begin(nets->specular_albedo);
+        if (rce == IRON_OK) rce = envelope_begin(nets->specular_roughness);
+        if (rce != IRON_OK) return rce;
+    }
     const ShadeLayout L = shade_layout(n);
     if (workspace_bytes < L.total) return IRON_ERR_WORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
@@ -1177,6 +1198,11 @@ extern "C" int iron_shade_ggx(const iron_shade_nets* nets, float light, int32_t 
     ma.out = rr;
     rc = launch_material(nets->specular_roughness, ma, max_tiles, st);
     if (rc != IRON_OK) return rc;
+    // envelope guard (envelope.hip): the values each network returned for the *count hits
+    envelope_scan(nets->sdf, grad, n, count, 3, st);
+    envelope_scan(nets->diffuse_albedo, kd, n, count, 3, st);
+    envelope_scan(nets->specular_albedo, ks, n, count, 3, st);
+    envelope_scan(nets->specular_roughness, rr, n, count, 1, st);
 
     ShadeArgs sa;
     sa.list = list; sa.count_ptr = count; sa.ray_o = ray_o; sa.ray_d = ray_d; sa.points = points; sa.grad = grad;

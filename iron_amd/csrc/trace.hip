@@ -670,6 +670,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     a0.lin = lin_steps; a0.conv = conv; a0.points = points; a0.sdf = sdf_out; a0.dist = dist;
     a0.ray0 = 0; a0.n = (int)n; a0.n_steps = p->n_steps; a0.iters = p->sphere_tracing_iters; a0.thr = p->sdf_threshold;
     a0.chunk = p->chunk > 0 ? p->chunk : 0;
+    if (phase == 0) { const int rce = envelope_begin(sdf); if (rce != IRON_OK) return rce; }
     const bool h2 = h2_sdf_usable(sdf);
 
     // the parts: rays [b_k, b_{k+1}), own counters, own stretch [b_k, ..) of every list (a part lists at most its own rays);
@@ -729,6 +730,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     }
     for (int k = 1; k < parts; ++k)   // join: everything behind this call on the caller's stream sees all parts finished
         if (bnd[k + 1] > bnd[k]) IRON_HIP_TRY(hipStreamWaitEvent(st, S->join[k - 1], 0));
+    if (phase == 1 && h2) envelope_scan(sdf, sdf_out, n, nullptr, 1, st);   // envelope guard (envelope.hip): every ray's last sdf value
     if (phase == 1 && stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w0, parts, p->n_steps, stats);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;

@@ -13,6 +13,7 @@ iron_amd.autograd (HIP forward + closed-form HIP backward); Ne
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -117,7 +118,38 @@ class _HipNet(nn.Module):
             _lib.check(lib.iron_net_create(C.byref(out), C.byref(desc), arr, _lib.stream_ptr(dev)))
         handle = _NetHandle(out.value, dev)
         self.__dict__["_hip_cache"] = (key, handle)
+        if self.__dict__.get("_force_exact"):
+            _lib.check(lib.iron_net_force_exact(handle.handle, 1))
         return handle
+
+    # ---- numeric envelope of the default (split-fp16, "h2") core: include/iron_hip.h, csrc/envelope.hip -----------------------
+    def numeric_status(self) -> dict:
+        """Synchronises the current stream and reports the packed network's envelope status: `overflow_seen` (some call on the h2
+        core returned non-finite values because an activation or feature left fp16's range), `exact_core` (the network runs on the
+        exact-fp32 MFMA core: after an overflow, or force_exact()), `pending` (the call that just finished overflowed; the next
+        one will run on the exact core)."""
+        h = self.hip_net()
+        st = C.c_int32(0)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.load().iron_net_numeric_status(h.handle, C.byref(st), _lib.stream_ptr(h.device)))
+        return {"overflow_seen": bool(st.value & 1), "exact_core": bool(st.value & 2), "pending": bool(st.value & 4)}
+
+    def force_exact(self, on: bool = True) -> None:
+        """Pin this network to the exact-fp32 MFMA core (survives re-packing), or return it to the default core."""
+        self.__dict__["_force_exact"] = bool(on)
+        _lib.check(_lib.load().iron_net_force_exact(self.hip_net().handle, 1 if on else 0))
+
+    def _rerun_if_overflowed(self, call):
+        """IRON_H2_OVERFLOW=rerun: pay one synchronisation per call, and when the call left the h2 core's range run it again (the
+        library has moved the network to the exact-fp32 core by then).  Default: no synchronisation -- the offending call returns
+        non-finite values and every later call is exact (numeric_status() tells)."""
+        out = call()
+        if _OVERFLOW_RERUN and self.numeric_status()["pending"]:
+            out = call()
+        return out
+
+
+_OVERFLOW_RERUN = os.environ.get("IRON_H2_OVERFLOW", "") == "rerun"
 
 
 # IDR-style SDF MLP (reference: models/fields.py:9-137)
@@ -194,9 +226,12 @@ class SDFNetwork(_HipNet):
         x = x.reshape(-1, 3)
         net = self.hip_net()
         out = torch.empty((x.shape[0], out_cols), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.load().iron_sdf_forward(net.handle, x.data_ptr(), x.shape[0], out.data_ptr(), out_cols,
-                                                    _lib.stream_ptr(x.device)))
+
+        def call():
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().iron_sdf_forward(net.handle, x.data_ptr(), x.shape[0], out.data_ptr(), out_cols,
+                                                        _lib.stream_ptr(x.device)))
+        self._rerun_if_overflowed(call)
         return out.reshape(sh + [out_cols])
 
     def sdf(self, x: torch.Tensor) -> torch.Tensor:
@@ -237,10 +272,12 @@ class SDFNetwork(_HipNet):
         sdf = torch.empty((n, 1), dtype=torch.float32, device=xx.device)
         feat = torch.empty((n, self.d_out - 1), dtype=torch.float32, device=xx.device)
         grad = torch.empty((n, 3), dtype=torch.float32, device=xx.device)
-        with torch.cuda.device(xx.device):
-            ws, ws_bytes = _get_all_workspace(net, n, xx.device)
-            _lib.check(_lib.load().iron_sdf_get_all(net.handle, xx.data_ptr(), n, sdf.data_ptr(), feat.data_ptr(),
-                                                    grad.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(xx.device)))
+        def call():
+            with torch.cuda.device(xx.device):
+                ws, ws_bytes = _get_all_workspace(net, n, xx.device)
+                _lib.check(_lib.load().iron_sdf_get_all(net.handle, xx.data_ptr(), n, sdf.data_ptr(), feat.data_ptr(),
+                                                        grad.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(xx.device)))
+        self._rerun_if_overflowed(call)
         return sdf.reshape(sh + [1]), feat.reshape(sh + [self.d_out - 1]), grad.reshape(sh + [3])
 
     @torch.no_grad()
@@ -339,9 +376,11 @@ class RenderingNetwork(_HipNet):
         ft = _lib.require_cuda_f32(feature_vectors.detach(), "feature_vectors").reshape(-1, self.d_feature)
         net = self.hip_net()
         out = torch.empty((n, self.d_out), dtype=torch.float32, device=p.device)
-        with torch.cuda.device(p.device):
-            _lib.check(_lib.load().iron_render_forward(net.handle, p.data_ptr(), _lib.ptr(nrm), _lib.ptr(vd),
-                                                       ft.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(p.device)))
+        def call():
+            with torch.cuda.device(p.device):
+                _lib.check(_lib.load().iron_render_forward(net.handle, p.data_ptr(), _lib.ptr(nrm), _lib.ptr(vd),
+                                                           ft.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(p.device)))
+        self._rerun_if_overflowed(call)
         return out.reshape(sh + [self.d_out])
 
 
