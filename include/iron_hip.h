@@ -327,6 +327,19 @@ int iron_trace(const iron_net_t* sdf, const iron_trace_params* p, const float* l
                uint8_t* conv, float* points, float* sdf_out, float* dist, iron_trace_stats* stats,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* The three stages of RayTracer.forward as separate calls, for callers that use the reference's methods directly (models/raytracer.py
+ * :105-140 sphere_tracing, :142-197 ray_sampler, :199-220 rootfind; tests/test_raytracer.py).  One call = one reference call: the
+ * bisection count is global to its n rays.  `workspace` as for iron_trace (iron_trace_workspace_bytes(n, p)).
+ *   stage 0 sphere_tracing: in0 = min_dis, in1 = max_dis, work  ->  mask_out = convergent, unfinished_out, points, sdf_out, dist
+ *   stage 1 ray_sampler:    in0 = min_dis, in1 = max_dis        ->  mask_out = rays with a bracketed root, points, sdf_out, dist
+ *                           (zeros for the others, as the reference returns them)
+ *   stage 2 rootfind:       in0 = f_low, in1 = f_high, in2 = d_low, in3 = d_high  ->  points = p_mid, dist = d_mid, sdf_out = f_mid
+ *                           (mask_out: scratch, n bytes; the reference's in-place update of its four bracket arguments is not made) */
+int iron_trace_stage(int32_t stage, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps, const float* ray_o,
+                     const float* ray_d, const float* in0, const float* in1, const float* in2, const float* in3, const uint8_t* work,
+                     int64_t n, uint8_t* mask_out, uint8_t* unfinished_out, float* points, float* sdf_out, float* dist,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Multi-rank form: rays of one reference chunk may live on several ranks, so the chunk-global
  * bisection count needs one MAX all-reduce between the two halves.  phase 0 = sphere trace +
  * sampler + per-ray bisection, writing each local chunk's own count to chunk_iters[n_chunks];

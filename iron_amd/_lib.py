@@ -122,6 +122,8 @@ SYMBOLS = {
     "iron_trace_workspace_bytes": (_SZ, [_I64, C.POINTER(iron_trace_params)]),
     "iron_trace": (C.c_int, [_P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                              _P, _SZ, _P]),
+    "iron_trace_stage": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
+                                   _P, _SZ, _P]),
     "iron_trace_phase": (C.c_int, [_I32, _P, C.POINTER(iron_trace_params), _P, _P, _P, _P, _P, _P, _P, _I64, _P,
                                    _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "iron_net_numeric_status": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),

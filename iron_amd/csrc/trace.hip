@@ -495,6 +495,34 @@ __global__ void k_trace_stats(TraceWs w, int n_parts, int n_steps, iron_trace_st
     }
 }
 
+// ---- single stages (iron_trace_stage: RayTracer.sphere_tracing / ray_sampler / rootfind as callable methods) ---------------------
+__global__ void k_stage_mark_list(const int* __restrict__ list, const int* __restrict__ count, uint8_t* __restrict__ mask) {
+    const int n = *count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) mask[list[i]] = 1;
+}
+
+// ray_sampler (raytracer.py:142-197) takes every ray of the call with its own interval [min_dis, max_dis]: the list is the
+// identity and the per-ray state the dense sampler reads is set so that it samples exactly that interval (sdf > 0: [dist, far])
+__global__ void k_stage_sampler_init(TraceArgs a, TraceWs w, const float* __restrict__ min_dis) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        w.sampler_list[i] = i;
+        a.dist[i] = min_dis[i];
+        a.sdf[i] = 1.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->n_sampler = a.n;
+}
+
+// rootfind (raytracer.py:199-220) on caller-given brackets
+__global__ void k_stage_root_init(TraceWs w, int n, const float* __restrict__ f_low, const float* __restrict__ f_high,
+                                  const float* __restrict__ d_low, const float* __restrict__ d_high) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        w.root_list[i] = i;
+        w.root_lo[i] = d_low[i]; w.root_hi[i] = d_high[i];
+        w.root_flo[i] = f_low[i]; w.root_fhi[i] = f_high[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->n_root = n;
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
@@ -732,6 +760,65 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         if (bnd[k + 1] > bnd[k]) IRON_HIP_TRY(hipStreamWaitEvent(st, S->join[k - 1], 0));
     if (phase == 1 && h2) envelope_scan(sdf, sdf_out, n, nullptr, 1, st);   // envelope guard (envelope.hip): every ray's last sdf value
     if (phase == 1 && stats) hipLaunchKernelGGL(k_trace_stats, dim3(1), dim3(64), 0, st, w0, parts, p->n_steps, stats);
+    IRON_HIP_TRY(hipGetLastError());
+    return IRON_OK;
+}
+
+extern "C" int iron_trace_stage(int32_t stage, const iron_net_t* sdf, const iron_trace_params* p, const float* lin_steps,
+                                const float* ray_o, const float* ray_d, const float* in0, const float* in1, const float* in2,
+                                const float* in3, const uint8_t* work, int64_t n, uint8_t* mask_out, uint8_t* unfinished_out,
+                                float* points, float* sdf_out, float* dist, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sdf || sdf->desc.kind != IRON_NET_SDF || !p || n < 0 || stage < 0 || stage > 2) return IRON_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL - 64) return IRON_ERR_BAD_ARG;
+    if (p->n_steps < 2 || p->n_steps > 4096 || p->sphere_tracing_iters < 0 || !(p->sdf_threshold > 0.0f)) return IRON_ERR_BAD_ARG;
+    if (n == 0) return IRON_OK;
+    if (!lin_steps || !ray_o || !ray_d || !in0 || !in1 || !mask_out || !points || !sdf_out || !dist || !workspace) return IRON_ERR_BAD_ARG;
+    if (stage == 0 && (!work || !unfinished_out)) return IRON_ERR_BAD_ARG;
+    if (stage == 2 && (!in2 || !in3)) return IRON_ERR_BAD_ARG;
+    iron_trace_params q = *p;
+    q.chunk = 0;   // one reference call = one chunk
+    const WsLayout L = ws_layout(n, &q);
+    if (workspace_bytes < L.total) return IRON_ERR_WORKSPACE;
+    if (((uintptr_t)workspace & 15) != 0) return IRON_ERR_BAD_ARG;
+    { const int rce = envelope_begin(sdf); if (rce != IRON_OK) return rce; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    TraceWs w;
+    w.cnt = (TraceCounters*)(base + L.cnt);
+    w.sampler_list = (int*)(base + L.sampler_list);
+    w.root_list = (int*)(base + L.root_list);
+    w.root_lo = (float*)(base + L.lo); w.root_hi = (float*)(base + L.hi);
+    w.root_flo = (float*)(base + L.flo); w.root_fhi = (float*)(base + L.fhi);
+    w.root_k = (int*)(base + L.k);
+    w.chunk_iters = (int*)(base + L.chunk_iters);
+    w.chunk_roots = (int*)(base + L.chunk_roots);
+    w.n_chunks = 1;
+    TraceArgs a;
+    a.ray_o = ray_o; a.ray_d = ray_d; a.work = work; a.ray_index = nullptr; a.lin = lin_steps;
+    a.conv = mask_out; a.points = points; a.sdf = sdf_out; a.dist = dist;
+    a.ray0 = 0; a.n = (int)n; a.n_steps = p->n_steps; a.iters = p->sphere_tracing_iters; a.thr = p->sdf_threshold; a.chunk = 0;
+    a.near = in0; a.far = in1;
+    const bool h2 = h2_sdf_usable(sdf);
+    IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, kCntStride * kMaxTraceSplits, st));
+    IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int)), st));
+    IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_roots, 0, align256(sizeof(int)), st));
+    const int64_t tiles = (n + 31) / 32;
+    const unsigned gb = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    if (stage == 0) {            // sphere_tracing (raytracer.py:105-140): in0 = min_dis, in1 = max_dis
+        IRON_HIP_TRY(hipMemsetAsync(unfinished_out, 0, (size_t)n, st));
+        launch_trace_kernel(0, h2, sdf, a, w, tiles, st);
+        hipLaunchKernelGGL(k_stage_mark_list, dim3(gb), dim3(256), 0, st, w.sampler_list, &w.cnt->n_sampler, unfinished_out);
+    } else if (stage == 1) {     // ray_sampler (:142-197): in0 = min_dis, in1 = max_dis, every ray sampled on its own interval
+        hipLaunchKernelGGL(k_stage_sampler_init, dim3(gb), dim3(256), 0, st, a, w, in0);
+        launch_trace_kernel(1, h2, sdf, a, w, (n + kSamplerSlots - 1) / kSamplerSlots, st);
+        launch_trace_kernel(2, h2, sdf, a, w, tiles, st);
+        launch_trace_kernel(3, h2, sdf, a, w, tiles, st);
+    } else {                     // rootfind (:199-220): in0 = f_low, in1 = f_high, in2 = d_low, in3 = d_high
+        hipLaunchKernelGGL(k_stage_root_init, dim3(gb), dim3(256), 0, st, w, (int)n, in0, in1, in2, in3);
+        launch_trace_kernel(2, h2, sdf, a, w, tiles, st);
+        launch_trace_kernel(3, h2, sdf, a, w, tiles, st);
+    }
+    if (h2) envelope_scan(sdf, sdf_out, n, nullptr, 1, st);
     IRON_HIP_TRY(hipGetLastError());
     return IRON_OK;
 }

@@ -138,6 +138,58 @@ class RayTracer(nn.Module):
         return {"convergent_mask": conv, "points": points, "sdf": sdf_out, "distance": dist}
 
 
+    # ---- the three stages as the reference exposes them (raytracer.py:105-220; tests/test_raytracer.py drives forward(), the
+    # methods are public API of the class): each is one iron_trace_stage call, i.e. the same persistent kernels forward() chains
+    def _stage(self, stage, sdf, ray_o, ray_d, in0, in1, in2=None, in3=None, work_mask=None):
+        o = _lib.require_cuda_f32(ray_o, "ray_o").reshape(-1, 3)
+        net = _resolve_sdf_network(sdf, o.device)
+        d = _lib.require_cuda_f32(ray_d, "ray_d").reshape(-1, 3)
+        ins = [None if t is None else _lib.require_cuda_f32(t, "argument").reshape(-1) for t in (in0, in1, in2, in3)]
+        n, dev = o.shape[0], o.device
+        work = None
+        if work_mask is not None:
+            if work_mask.dtype != torch.bool or not work_mask.is_cuda:
+                raise _lib.IronError("work_mask must be a CUDA bool tensor")
+            work = work_mask.reshape(-1).contiguous()
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        unfinished = torch.zeros(n, dtype=torch.bool, device=dev)
+        points = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        sdf_out = torch.zeros(n, dtype=torch.float32, device=dev)
+        dist = torch.zeros(n, dtype=torch.float32, device=dev)
+        if n > 0:
+            lib = _lib.load()
+            prm = self._params(0)
+            ws_bytes = lib.iron_trace_workspace_bytes(n, C.byref(prm))
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            lin = _linspace_steps(self.n_steps, dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.iron_trace_stage(stage, net.hip_net().handle, C.byref(prm), lin.data_ptr(), o.data_ptr(), d.data_ptr(),
+                                                _lib.ptr(ins[0]), _lib.ptr(ins[1]), _lib.ptr(ins[2]), _lib.ptr(ins[3]), _lib.ptr(work), n,
+                                                mask.data_ptr(), unfinished.data_ptr(), points.data_ptr(), sdf_out.data_ptr(),
+                                                dist.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)))
+        return mask, unfinished, points, sdf_out, dist
+
+    @torch.no_grad()
+    def sphere_tracing(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask):
+        """raytracer.py:105-140 -> (convergent_mask, unfinished_mask_start, curr_start_points, curr_sdf_start, acc_start_dis)."""
+        conv, unfinished, points, s, t = self._stage(0, sdf, ray_o, ray_d, min_dis, max_dis, work_mask=work_mask)
+        return conv, unfinished, points, s, t
+
+    @torch.no_grad()
+    def ray_sampler(self, sdf, ray_o, ray_d, min_dis, max_dis):
+        """raytracer.py:142-197: n_steps samples on [min_dis, max_dis] of every ray, first sign change, rootfind ->
+        (rootfind_work_mask, sampler_pts, sampler_sdf, sampler_dis); rays without a bracketed root hold zeros."""
+        mask, _, points, s, t = self._stage(1, sdf, ray_o, ray_d, min_dis, max_dis)
+        return mask, points, s, t
+
+    @torch.no_grad()
+    def rootfind(self, sdf, f_low, f_high, d_low, d_high, ray_o, ray_d):
+        """raytracer.py:199-220: bisection of every bracket while ANY of the call's brackets is wider than 2 x sdf_threshold ->
+        (p_mid, d_mid, f_mid).  (The reference also narrows d_low / d_high / f_low / f_high in place; callers of this class do not
+        read them afterwards and this method leaves them alone.)"""
+        _, _, points, s, t = self._stage(2, sdf, ray_o, ray_d, f_low, f_high, d_low, d_high)
+        return points, t, s
+
     @torch.no_grad()
     def phase_begin(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, ray_index, n_chunks, chunk, collect_stats: bool = False):
         """First half of the multi-rank form of forward(): sphere tracing, dense sampling and each ray's own bisection

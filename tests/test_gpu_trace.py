@@ -148,3 +148,71 @@ def test_split_form_is_bit_equal():
     finally:
         RT.VERBOSE_MODE = old
         lib.iron_set_trace_split(prev)
+
+
+@torch.no_grad()
+def test_stage_methods_match_the_oracle():
+    """RayTracer.sphere_tracing / ray_sampler / rootfind as callable methods (raytracer.py:105-220; VERDICT r2 'missing' 3): each
+    against the oracle's restatement of the same lines on the rays of a 96x96 view of S1 -- masks equal, values within the
+    tracer's tolerance (abs(d distance) <= 2e-4, as test_trace_matches_reference), and chained by hand they reproduce forward()."""
+    from iron_amd.raytracer import Camera, RayTracer, SDFHandle, intersect_sphere
+    dev = torch.device("cuda", 0)
+    nets_cpu = scenes.build_networks("S1")
+    sc = oracle_scene(nets_cpu)
+    net = nets_cpu["sdf_network"].to(dev)
+    K, W2C = scenes.fixture_camera_matrices(96, 96)
+    cam = Camera(96, 96, K.to(dev), W2C.to(dev))
+    ro, rd, _ = cam.get_rays(cam.get_uv())
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    hit, near, far = intersect_sphere(ro, rd, 1.0)
+    tr = RayTracer()
+    h = SDFHandle(net)
+    prm = R.TracerParams()
+    sdf_fn = lambda x: R.sdf_forward(sc.sdf_sd, sc.sdf_spec, x)[:, 0]
+    c_ro, c_rd, c_near, c_far, c_hit = ro.cpu(), rd.cpu(), near.cpu(), far.cpu(), hit.cpu()
+
+    # sphere_tracing
+    conv, unf, p, s, t = tr.sphere_tracing(h, ro, rd, near, far, hit)
+    rconv, runf, rp, rs, rt = R.sphere_tracing(sdf_fn, c_ro, c_rd, c_near, c_far, c_hit, prm)
+    assert int((conv.cpu() != rconv).sum()) <= 2 and int((unf.cpu() != runf).sum()) <= 2
+    both = (conv.cpu() & rconv)
+    assert float((t.cpu() - rt)[both].abs().max()) <= 2e-4
+    same = ~(conv.cpu() ^ rconv) & ~(unf.cpu() ^ runf)
+    assert float((s.cpu() - rs)[same & ~runf].abs().max()) <= 2e-4
+    assert int(unf.sum()) > 500 and int(conv.sum()) > 500
+
+    # ray_sampler on the oracle's unfinished rays (same inputs on both sides)
+    m = runf
+    pos = (rs[m] > 0.0).float()
+    s_min = pos * rt[m] + (1.0 - pos) * c_near[m]
+    s_max = pos * c_far[m] + (1.0 - pos) * rt[m]
+    rroot, rsp, rss, rst, _ = R.ray_sampler(sdf_fn, c_ro[m], c_rd[m], s_min.clone(), s_max.clone(), prm)
+    root, sp, ss, st = tr.ray_sampler(h, c_ro[m].to(dev), c_rd[m].to(dev), s_min.to(dev), s_max.to(dev))
+    assert int((root.cpu() != rroot).sum()) <= 2
+    bothr = root.cpu() & rroot
+    assert int(bothr.sum()) > 50
+    assert float((st.cpu() - rst)[bothr].abs().max()) <= 2e-4 and float((sp.cpu() - rsp)[bothr].abs().max()) <= 2e-4
+    nor = ~root.cpu() & ~rroot
+    assert float(st.cpu()[nor].abs().max()) == 0.0 and float(sp.cpu()[nor].abs().max()) == 0.0 and float(ss.cpu()[nor].abs().max()) == 0.0
+
+    # rootfind on hand-made brackets around the oracle's roots (and two brackets that need no iteration)
+    k = int(bothr.sum())
+    d_lo = (rst[bothr] - 0.013).clone(); d_hi = (rst[bothr] + 0.011).clone()
+    oo, dd = c_ro[m][bothr], c_rd[m][bothr]
+    f_lo = sdf_fn(oo + dd * d_lo.unsqueeze(-1)); f_hi = sdf_fn(oo + dd * d_hi.unsqueeze(-1))
+    f_lo[:2] = -1.0   # not a bracket: these two rays make no step of their own but are moved by the call's shared loop
+    want_p, want_d, want_f, _ = R.rootfind(sdf_fn, f_lo.clone(), f_hi.clone(), d_lo.clone(), d_hi.clone(), oo, dd, prm)
+    got_p, got_d, got_f = tr.rootfind(h, f_lo.to(dev), f_hi.to(dev), d_lo.to(dev), d_hi.to(dev), oo.to(dev), dd.to(dev))
+    assert got_p.shape == (k, 3) and got_d.shape == (k,)
+    assert float((got_d.cpu() - want_d).abs().max()) <= 2e-4 and float((got_f.cpu() - want_f).abs().max()) <= 2e-4
+
+    # chained like raytracer.py:45-79 the stages give forward()'s result exactly (same kernels, same order)
+    full = tr(h, ro, rd, near, far, hit)
+    mm = unf
+    posg = (s[mm] > 0.0).float()
+    g_min = posg * t[mm] + (1.0 - posg) * near[mm]
+    g_max = posg * far[mm] + (1.0 - posg) * t[mm]
+    r2, p2, s2, t2 = tr.ray_sampler(h, ro[mm], rd[mm], g_min, g_max)
+    conv[mm] = r2; p[mm] = p2; s[mm] = s2; t[mm] = t2
+    assert torch.equal(conv, full["convergent_mask"]) and torch.equal(t, full["distance"]) and torch.equal(s, full["sdf"])
+    assert torch.equal(p, full["points"])

@@ -28,9 +28,6 @@ NOT_BUILT = {
     ("models.renderer_ggx", "calc_dist_params"): "helper of the anisotropic branch CompositeRenderer never takes (has_anisotropic=False); folded into ggx_core.h",
     ("models.renderer_ggx", "fresnel_conductor_exact"): "internal helper of the conductor heads: lives in csrc/ggx_core.h (tested through G9)",
     ("models.renderer_ggx", "fresnel_dielectric"): "internal helper of the dielectric heads: lives in csrc/ggx_core.h (tested through G9)",
-    ("models.raytracer", "RayTracer", "sphere_tracing"): "fused: iron_trace's k_sphere (one launch for all iterations, no per-iteration masks to hand back)",
-    ("models.raytracer", "RayTracer", "ray_sampler"): "fused: iron_trace's k_sampler",
-    ("models.raytracer", "RayTracer", "rootfind"): "fused: iron_trace's k_bisect_a / k_bisect_b",
 }
 
 
