@@ -359,15 +359,50 @@ class Camera(object):
         return sub, cut[0], cut[1]
 
     def resize(self, factor, image=None):
-        """raytracer.py:353-364 -> (camera, image): intrinsics rows 0 / 1 scaled by the (integer-truncated) size ratio.
-        Resampling an image (cv2.INTER_AREA in the reference) is dataset I/O and out of scope here."""
-        if image is not None:
-            raise NotImplementedError("Camera.resize(image=...) needs cv2.INTER_AREA resampling (dataset I/O, out of scope)")
+        """raytracer.py:353-364 -> (camera, image): intrinsics rows 0 / 1 scaled by the (integer-truncated) size ratio; `image`
+        ([H,W] or [H,W,C]; tensor or numpy array) resampled to the new size the way cv2.INTER_AREA does when shrinking: every
+        output pixel is the coverage-weighted mean of the input pixels its footprint overlaps (exact box average for integer
+        ratios).  cv2 is not installed in the build container, so this resampling is parity-unpinned against OpenCV itself
+        (tests hold it to the closed form).  Enlarging (factor > 1), where INTER_AREA degenerates to an interpolation, uses
+        bilinear interpolation."""
         new_H, new_W = int(self.H * factor), int(self.W * factor)
         K = self.K.clone()
         for row, ratio in ((0, new_W / self.W), (1, new_H / self.H)):
             K[row, :3] = K[row, :3] * ratio
-        return Camera(new_W, new_H, K, self.W2C.clone()), None
+        cam = Camera(new_W, new_H, K, self.W2C.clone())
+        if image is None:
+            return cam, None
+        as_numpy = isinstance(image, np.ndarray)
+        img = torch.as_tensor(image)
+        orig_dtype = img.dtype
+        x = img.to(torch.float64 if img.dtype == torch.float64 else torch.float32)
+        squeeze = x.dim() == 2
+        if squeeze:
+            x = x.unsqueeze(-1)
+        if x.shape[0] != self.H or x.shape[1] != self.W:
+            raise AssertionError("image size does not match specified size")
+        if new_H <= self.H and new_W <= self.W:
+            x = torch.einsum("ih,hwc->iwc", _area_weights(self.H, new_H, x), x)
+            x = torch.einsum("jw,iwc->ijc", _area_weights(self.W, new_W, x), x)
+        else:
+            x = torch.nn.functional.interpolate(x.permute(2, 0, 1).unsqueeze(0), size=(new_H, new_W), mode="bilinear",
+                                                align_corners=False)[0].permute(1, 2, 0)
+        if squeeze:
+            x = x[..., 0]
+        if not orig_dtype.is_floating_point:
+            x = x.round().clamp(torch.iinfo(orig_dtype).min, torch.iinfo(orig_dtype).max)
+        x = x.to(orig_dtype)
+        return cam, (x.cpu().numpy() if as_numpy else x)
+
+
+def _area_weights(n_in: int, n_out: int, like: torch.Tensor) -> torch.Tensor:
+    """[n_out, n_in] coverage weights of the shrinking box filter: output cell i covers [i s, (i+1) s) of the input, s = n_in / n_out."""
+    s = n_in / n_out
+    lo = torch.arange(n_out, dtype=torch.float64).unsqueeze(1) * s
+    hi = lo + s
+    j = torch.arange(n_in, dtype=torch.float64).unsqueeze(0)
+    w = (torch.minimum(hi, j + 1.0) - torch.maximum(lo, j)).clamp_min(0.0) / s
+    return w.to(dtype=like.dtype, device=like.device)
 
 
 @torch.no_grad()
@@ -492,7 +527,21 @@ def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_si
     else:
         edge_points = torch.zeros((0, 3), dtype=torch.float32, device=dev)
         edge_uv = torch.zeros((0, 2), dtype=torch.float32, device=dev)
-    return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
+    out = {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
+    if VERBOSE_MODE:  # the reference's debug maps (raytracer.py:515-537)
+        walk_edge_found_mask = torch.zeros_like(mask)
+        walk_edge_found_mask[mask] = found
+        edge_angles = torch.zeros(camera.H, camera.W, dtype=torch.float32, device=dev)
+        edge_sdf = torch.zeros(camera.H, camera.W, 1, dtype=torch.float32, device=dev)
+        if update_pixels.shape[0] > 0:
+            view = camera.get_camera_origin().reshape(1, 3) - edge_points
+            view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+            sdf_vals, grads = sdf_network.get_sdf_and_gradient(edge_points)
+            nrm = grads / (grads.norm(dim=-1, keepdim=True) + 1e-10)
+            edge_angles.view(-1)[update_pixels] = torch.rad2deg(torch.acos((view * nrm).sum(dim=-1)))
+            edge_sdf.view(-1)[update_pixels] = sdf_vals.squeeze(-1)
+        out.update({"walk_edge_found_mask": walk_edge_found_mask, "edge_angles": edge_angles, "edge_sdf": edge_sdf})
+    return out
 
 
 def fill_depth_holes(results):
@@ -662,8 +711,11 @@ def _edge_side_colours(results, camera, sdf_network, raytracer, color_network_di
                                        weight.data_ptr(), _lib.stream_ptr(dev)))
     both = _side_rays(results, n_edge, sdf_network, raytracer, camera, side_uv, color_network_dict, render_fn, False)
     side_color = _lib.require_cuda_f32(both["color"], "color").reshape(2 * n_edge, 3)
-    return {"n_edge": n_edge, "edge_points": edge_points, "edge_uv": edge_uv, "pixel": pixel, "edge_grads": edge_grads, "weight": weight,
-            "side_color": side_color, "pos_neg_normal": both["normal"][both["convergent_mask"]]}
+    ctx = {"n_edge": n_edge, "edge_points": edge_points, "edge_uv": edge_uv, "pixel": pixel, "edge_grads": edge_grads, "weight": weight,
+           "side_color": side_color, "pos_neg_normal": both["normal"][both["convergent_mask"]]}
+    if VERBOSE_MODE:
+        ctx["verbose"] = {"side_uv": side_uv, "side_depth": both["depth"].reshape(-1)}
+    return ctx
 
 
 def _edge_blend(results, ctx):
@@ -681,6 +733,23 @@ def _edge_blend(results, ctx):
                                        results["color"].data_ptr(), results["normal"].data_ptr(), results["uv"].data_ptr(),
                                        results["points"].data_ptr(), _lib.stream_ptr(dev)))
     results["edge_pos_neg_normal"] = ctx["pos_neg_normal"]
+    if VERBOSE_MODE and "verbose" in ctx:  # the reference's debug maps (raytracer.py:731-775)
+        v, pixel = ctx["verbose"], ctx["pixel"]
+        shape = list(results["edge_mask"].shape)
+        maps = {}
+        for key, vals, ch in (("edge_pos_side_weight", ctx["weight"], None), ("edge_pos_side_depth", v["side_depth"][:n_edge], None),
+                              ("edge_neg_side_depth", v["side_depth"][n_edge:], None),
+                              ("edge_pos_side_color", ctx["side_color"][:n_edge], 3), ("edge_neg_side_color", ctx["side_color"][n_edge:], 3)):
+            img = torch.zeros(shape + ([ch] if ch else []), dtype=torch.float32, device=dev)
+            if ch:
+                img.view(-1, ch)[pixel] = vals
+            else:
+                img.view(-1)[pixel] = vals
+            maps[key] = img
+        maps["pos_side_uv"], maps["neg_side_uv"] = v["side_uv"][:n_edge], v["side_uv"][n_edge:]
+        half = 0.5 * (maps["neg_side_uv"] - maps["pos_side_uv"])          # = PIXEL_RADIUS * edge_normals2d (raytracer.py:693-694)
+        maps["edge_normals2d"] = half / (half.norm(dim=-1, keepdim=True) + 1e-10)
+        results.update(maps)
 
 
 def _render_edge_pixels_training(results, camera, sdf_network, raytracer, color_network_dict, render_fn):

@@ -145,3 +145,30 @@ def test_tile_sharding_partitions_the_image():
     rec[..., 0] = 1.0
     d = split_record(rec)
     assert d["convergent_mask"].dtype == torch.bool and d["color"].shape == (4, 4, 3) and d["depth"].shape == (4, 4)
+
+
+def test_camera_resize_resamples_the_image_by_area():
+    """Camera.resize(factor, image) (models/raytracer.py:353-364, cv2.INTER_AREA there): shrinking by an integer ratio is the exact
+    box mean, by a fractional ratio the coverage-weighted mean (constant images stay constant, the total is preserved), dtypes and
+    array kinds come back as given.  (cv2 is absent from the build container: parity-unpinned against OpenCV itself.)"""
+    import numpy as np
+    import torch
+    from iron_amd.raytracer import Camera
+    K = torch.eye(4); K[0, 0] = K[1, 1] = 100.0; K[0, 2], K[1, 2] = 32.0, 24.0
+    cam = Camera(64, 48, K, torch.eye(4))
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(48, 64, 3, generator=g)
+    c2, small = cam.resize(0.25, image=img)
+    assert (c2.W, c2.H) == (16, 12) and small.shape == (12, 16, 3)
+    want = img.reshape(12, 4, 16, 4, 3).mean(dim=(1, 3))
+    assert float((small - want).abs().max()) <= 1e-6
+    assert abs(float(c2.K[0, 0]) - 25.0) < 1e-6 and abs(float(c2.K[1, 2]) - 6.0) < 1e-6
+    c3, frac = cam.resize(0.4, image=img[..., 0])          # 64 -> 25, 48 -> 19: fractional footprints
+    assert frac.shape == (19, 25)
+    assert abs(float(frac.mean()) - float(img[..., 0].mean())) <= 2e-3
+    _, const = cam.resize(0.4, image=torch.full((48, 64), 0.37))
+    assert float((const - 0.37).abs().max()) <= 1e-6
+    _, u8 = cam.resize(0.5, image=(img.numpy() * 255).astype(np.uint8))
+    assert isinstance(u8, np.ndarray) and u8.dtype == np.uint8 and u8.shape == (24, 32, 3)
+    cam_only, none = cam.resize(0.5)
+    assert none is None and cam_only.W == 32

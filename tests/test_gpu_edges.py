@@ -218,3 +218,48 @@ def test_skip_layer_material_net_keeps_the_one_stream_order():
     finally:
         RT.EDGE_OVERLAP = old
         RT._render_camera_overlapped = orig
+
+
+@torch.no_grad()
+def test_verbose_mode_debug_maps():
+    """VERBOSE_MODE (models/raytracer.py:14) adds the reference's debug maps to the result dict: depth_grad_norm / depth_edge_mask
+    (:587-589), walk_edge_found_mask / edge_angles / edge_sdf (:515-537), the side-ray maps of render_edge_pixels (:731-775).
+    Shapes and definitions are checked against the quantities they are made of; the rendered image itself must not change."""
+    from iron_amd import raytracer as RT
+    dev = torch.device("cuda", 0)
+    nets = {k: v.to(dev) for k, v in scenes.build_networks("S1").items()}
+    size = 128
+    K, W2C = scenes.fixture_camera_matrices(size, size)
+    cam = Camera(size, size, K.to(dev), W2C.to(dev))
+    fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    plain = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+    old = RT.VERBOSE_MODE
+    try:
+        RT.VERBOSE_MODE = True
+        res = render_camera(cam, nets["sdf_network"], RayTracer(), nets, fn, fill_holes=True, handle_edges=True)
+    finally:
+        RT.VERBOSE_MODE = old
+    for k in plain:
+        assert torch.equal(res[k], plain[k]), k
+    n_edge = int(res["edge_uv"].shape[0])
+    assert n_edge > 50
+    for k, shape in (("depth_grad_norm", (size, size)), ("depth_edge_mask", (size, size)), ("walk_edge_found_mask", (size, size)),
+                     ("edge_angles", (size, size)), ("edge_sdf", (size, size, 1)), ("edge_pos_side_weight", (size, size)),
+                     ("edge_pos_side_depth", (size, size)), ("edge_neg_side_depth", (size, size)),
+                     ("edge_pos_side_color", (size, size, 3)), ("edge_neg_side_color", (size, size, 3)),
+                     ("edge_normals2d", (n_edge, 2)), ("pos_side_uv", (n_edge, 2)), ("neg_side_uv", (n_edge, 2))):
+        assert tuple(res[k].shape) == shape, (k, tuple(res[k].shape))
+    em = res["edge_mask"]
+    assert bool((res["walk_edge_found_mask"] <= res["depth_edge_mask"]).all())          # found candidates are candidates
+    ang = res["edge_angles"][em]
+    assert float((ang - 90.0).abs().max()) <= 3.0                                        # |n.v| <= 0.05 at an edge point
+    assert float(res["edge_sdf"][em].abs().max()) <= 5e-3 and float(res["edge_angles"][~em].abs().max()) == 0.0
+    w = res["edge_pos_side_weight"][em]
+    assert float(w.min()) >= 0.5 - 1e-6 and float(w.max()) <= 1.0 + 1e-6                 # the chord never cuts off more than half the disc
+    # the blended colour of an edge pixel is the weighted mean of its two side colours (raytracer.py:709)
+    mix = res["edge_pos_side_color"] * res["edge_pos_side_weight"][..., None] + res["edge_neg_side_color"] * (1 - res["edge_pos_side_weight"][..., None])
+    assert float((mix[em] - res["color"][em]).abs().max()) <= 1e-5
+    centre = res["edge_uv"].floor() + 0.5
+    assert float(((res["pos_side_uv"] + res["neg_side_uv"]) / 2 - centre).abs().max()) <= 1e-4
+    assert float(((res["neg_side_uv"] - res["pos_side_uv"]).norm(dim=-1) - 2 * 0.707).abs().max()) <= 1e-4
+    assert float((res["edge_normals2d"].norm(dim=-1) - 1).abs().max()) <= 1e-5

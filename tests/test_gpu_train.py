@@ -17,9 +17,15 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def _compare_param_grads(module, leaf_sd, tol, tag):
+def _compare_param_grads(module, leaf_sd, tol, tag, tol_for=None):
+    """tol_for: {parameter-name prefix: tolerance} overrides for individual tensors (every other tensor is held to `tol`)."""
     worst = 0.0
+    base_tol = tol
     for name, p in module.named_parameters():
+        tol = base_tol
+        for prefix, t_ in (tol_for or {}).items():
+            if name.startswith(prefix):
+                tol = t_
         assert p.grad is not None, name
         ref = leaf_sd[name].grad
         if ref is None:  # torch found no path to this parameter (e.g. the last bias from a gradient-only loss): ours must be 0
@@ -184,7 +190,8 @@ def test_render_network_backward_vs_autograd(name):
     # the 8-layer colour net: layers 2..8 agree to 2e-7 ... 9e-7 (tests/diag_stage1_grads.py); ONE of the 1.16 M layer-1 pre-activations of
     # this batch lies within rounding of 0 and the backward's recomputed forward (split-fp16 GEMM, tests/test_gpu_gemm.py: 1-3e-7 per
     # product) lands on the other side of ReLU's kink than MKL's: that single element is 6.7e-4 of |dZ_1|, hence of lin1 / lin0's gradients
-    w = _compare_param_grads(net, sd, 1.5e-3 if name == "stage1_color" else 2e-4, name)
+    # -> only lin0 / lin1 of that net are allowed the kink element; everything else stays at 2e-4
+    w = _compare_param_grads(net, sd, 2e-4, name, tol_for={"lin0.": 1.5e-3, "lin1.": 1.5e-3} if name == "stage1_color" else None)
     for i, what in enumerate(("points", "normals", "view_dirs", "features")):
         if cpu_in[i].grad is None:
             assert gpu_in[i].grad is None or float(gpu_in[i].grad.abs().max()) == 0.0, what
