@@ -157,12 +157,36 @@ def rendezvous_only(a, world, rank):
     dist.destroy_process_group()
 
 
-def _host_threads():
+def _cpu_share():
+    """(cores this job may actually run on, details): the scheduler affinity, cut to the cgroup CPU quota when there is one -- the
+    GPU box shows all 256 hardware threads of its host in the affinity mask but grants a job a 16-core share (256 torch threads on
+    that share run ~20x slower than 16: the first attempt at "all host cores" did not finish)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, int(os.environ.get("IRON_CPU_THREADS", avail)))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                           # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    share = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
+    if quota is None and avail > 64:
+        share = 16    # no quota visible but a whole-host mask: the documented share of a one-GPU job on this pool
+    return share, {"affinity_cores": avail, "cpu_count": os.cpu_count(), "cgroup_quota_cores": quota}
+
+
+def _host_threads():
+    return max(1, int(os.environ.get("IRON_CPU_THREADS", _cpu_share()[0])))
 
 
 def _c2_cpu_baseline(threads):
@@ -332,16 +356,11 @@ def cpu_baseline(scene: str, res: int):
     from oracle import iron_ref as R
     from iron_amd import scenes
     from _util import oracle_scene
-    # every core this job may use: the GPU box gives one job a share of a much larger host (sched_getaffinity), which is what
-    # os.cpu_count() alone would overstate; IRON_CPU_THREADS overrides
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, int(os.environ.get("IRON_CPU_THREADS", avail)))
+    # every core this job may use (_cpu_share: affinity cut to the cgroup quota); IRON_CPU_THREADS overrides
+    share, host = _cpu_share()
+    threads = max(1, int(os.environ.get("IRON_CPU_THREADS", share)))
     torch.set_num_threads(threads)
-    print("[bench] cpu_baseline: oracle on %d threads (affinity %d, cpu_count %s)" % (threads, avail, os.cpu_count()),
-          file=sys.stderr, flush=True)
+    print("[bench] cpu_baseline: oracle on %d threads (%s)" % (threads, host), file=sys.stderr, flush=True)
     sc = oracle_scene(scenes.build_networks(scene))
     K512, W2C512 = scenes.fixture_camera_matrices(512, 512)
     c0 = R.CameraSpec(512, 512, K512, W2C512).crop(64, 64, (224, 224))
@@ -360,7 +379,7 @@ def cpu_baseline(scene: str, res: int):
             "E_per_ray": sc.counter.evals / (res * res), "H_per_ray": float(out["convergent_mask"].float().mean()),
             "c0": {"value": 64 * 64 / dt0 / 1e6, "unit": "Mrays/s", "seconds": dt0,
                    "sample": "BASELINE config C0: 64x64 crop, ul = (224, 224), of the 512x512 fixture camera (all rays hit: 8 evaluations per ray)"},
-            "host": {"affinity_cores": avail, "cpu_count": os.cpu_count()}}
+            "host": host}
 
 
 def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=6):

@@ -33,6 +33,9 @@
 #ifndef IRON_H2_RING_AHEAD
 #define IRON_H2_RING_AHEAD 3
 #endif
+#ifndef IRON_H2_ABL
+#define IRON_H2_ABL 0          // timing ablations (garbage results): 1 = half of the A-fragment LDS reads, 2 = no staged epilogue VALU
+#endif
 #ifndef IRON_H2_ROT_ISSUE
 #define IRON_H2_ROT_ISSUE 0    // experiment: ONE wave (in rotation) issues all 32 LDS-DMA pieces of a slot instead of 8 per wave
 #endif
@@ -530,20 +533,32 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
     // keeps hipcc from re-clustering (left alone it issues the 48 MFMAs first and the ~200 VALU ops afterwards).
     static_assert(FAST || EPI == 0, "the staged epilogue implements the v_exp/v_log softplus");
     EpiState es;
+#if IRON_H2_ABL & 2
+    // (timing only) the skipped epilogue's outputs are still defined values, so that nothing downstream folds away
+#pragma unroll
+    for (int i = 0; i < 16; ++i) es.z[i] = p_hi[i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            es.oh[q][i] = __builtin_bit_cast(unsigned, p_hi[4 * q + i]) & 0x3bff3bffu;   // finite fp16 pairs
+            es.ol[q][i] = __builtin_bit_cast(unsigned, p_lo[4 * q + i]) & 0x3bff3bffu;
+        }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        if (ks + kFragAhead < 16) {  // fragments of k-step ks + kFragAhead: in flight while this and the next steps' MFMAs run
+        if (ks + kFragAhead < 16 && (!(IRON_H2_ABL & 1) || ((ks + kFragAhead) & 1) == 0)) {  // fragments of k-step ks + kFragAhead: in flight while this and the next steps' MFMAs run
             fhs[(ks + kFragAhead) % kSets] = lds_frag(rd, 2 * (ks + kFragAhead), lane);
             fls[(ks + kFragAhead) % kSets] = lds_frag(rd, 2 * (ks + kFragAhead) + 1, lane);
         }
         const half8 fh = fhs[ks % kSets], fl = fls[ks % kSets];
         const int ti = ks >> 1, s = ks & 1;
         acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
-        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
         acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
-        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
-        if constexpr (EPI != 0) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
         if constexpr (CARRY) {
             static_assert(!CARRY || EPI == 1, "a carried tile ends as split fragments");
             if (ks == 12) {
