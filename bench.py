@@ -382,7 +382,7 @@ def cpu_baseline(scene: str, res: int):
             "host": host}
 
 
-def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=6):
+def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=4):
     """One-GPU PREDICTION for the multi-GPU target (no collectives in it): for world = 2, 4, 8 every rank's tile shard of the frame is
     run on this card the way the rank runs it -- its rank-local phases of ShardedRenderer (trace_begin -> trace_finish -> shade) back
     to back, `steps` steps without a host sync in between -- and T(frame) / max_r T(rank r step) is the strong-scaling factor the
@@ -401,12 +401,16 @@ def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps
                 return sh.shade(sh.trace_finish(sh.trace_begin([cam])))
             for _ in range(2):
                 step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize()
-            ms.append((time.perf_counter() - t0) / steps * 1e3)
+            best = None
+            for _ in range(3):   # best of 3 runs of `steps` steps: a caching-allocator stall (new 256 MiB blocks) inflates single runs 2x
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t0) / steps * 1e3
+                best = t if best is None else min(best, t)
+            ms.append(best)
         asm = min(render_emulated(world, [cam], sdf, nets, fn, tracer_factory, tile=SHARD_TILE)[2] for _ in range(2))
         out["n%d" % world] = {"rank_step_ms": [round(x, 3) for x in ms], "max_rank_step_ms": max(ms), "mean_rank_step_ms": sum(ms) / world,
                               "assemble_ms": asm, "factor": frame_ms / max(ms), "factor_with_assemble": frame_ms / (max(ms) + asm)}
