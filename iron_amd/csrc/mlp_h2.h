@@ -33,6 +33,10 @@
 #ifndef IRON_H2_RING_AHEAD
 #define IRON_H2_RING_AHEAD 3
 #endif
+#ifndef IRON_H2_SPREAD
+#define IRON_H2_SPREAD 1       // round 3: stage 0 of the staged epilogue pinned into its three gaps (its 16 fma otherwise all land behind the
+                               // step's first MFMA), and the finished fragments parked in AGPRs under k-steps 13 / 14 instead of behind the last MFMA
+#endif
 #ifndef IRON_H2_ABL
 #define IRON_H2_ABL 0          // timing ablations (garbage results): 1 = half of the A-fragment LDS reads, 2 = no staged epilogue VALU
 #endif
@@ -461,7 +465,13 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
     constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
     constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
     const int a16 = epi_lo(16, part), b16 = epi_hi(16, part), a8 = epi_lo(8, part), b8 = epi_hi(8, part);
+#if IRON_H2_SPREAD
+    // the inputs are a finished accumulator tile: nothing keeps the compiler from computing all 16 fma behind the first MFMA, so the
+    // operand is pinned to its part as well
+    if (ks == 0) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { float lo = p_lo[i]; pin1(lo); st.z[i] = fmaf(lo, kLoInv, p_hi[i]); pin1(st.z[i]); } }
+#else
     if (ks == 0) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.z[i] = fmaf(p_lo[i], kLoInv, p_hi[i]); pin1(st.z[i]); } }
+#endif
     if constexpr (ACT == 0) {
         if (ks == 1) { _Pragma("unroll") for (int i = a16; i < b16; ++i) { st.e[i] = __builtin_fabsf(st.z[i]) * -kC1; pin1(st.e[i]); } }
         if (ks == 2) { _Pragma("unroll") for (int i = a8; i < b8; ++i) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); pin1(st.e[i]); } }
@@ -570,6 +580,12 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
                 }
             }
         }
+#if IRON_H2_SPREAD
+        if constexpr (EPI == 1 && !CARRY) {   // the fragments are final behind stage 12: park them in the AGPR file under the MFMAs of k-steps 13 / 14
+            if (ks == 13) asm volatile("" : "+a"(es.oh[0]), "+a"(es.ol[0]));
+            if (ks == 14) asm volatile("" : "+a"(es.oh[1]), "+a"(es.ol[1]));
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) h2_stamp(rec, 2);
         if (ks == 7) h2_stamp(rec, 3);
