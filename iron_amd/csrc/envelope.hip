@@ -11,6 +11,9 @@
 // call that overflowed has returned non-finite values -- loud, not plausible-looking -- and the callers that can afford a
 // synchronisation re-run it (iron_amd/fields.py: IRON_H2_OVERFLOW=rerun).
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
 #include "iron_common.h"
 
 namespace iron {
@@ -37,19 +40,45 @@ static int overflow_mode() {   // 0 = move the network to the exact core (defaul
     return m;
 }
 
+// Flag words come from one pinned, device-mapped page pool per process: a training loop re-packs its networks every step, and a
+// hipHostMalloc / hipHostFree pair per handle would put a host-side map / unmap (and the implicit synchronisation of the free) into
+// every step.
+namespace {
+std::mutex g_pool_mu;
+int* g_pool_host = nullptr;
+int* g_pool_dev = nullptr;
+std::vector<int> g_pool_free;
+constexpr int kPoolSlots = 4096, kSlotInts = 16;   // 64 bytes per flag: one cache line each
+}  // namespace
+
 int envelope_create(iron_net* net) {
-    void* h = nullptr;
-    IRON_HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
-    *(volatile int*)h = 0;
-    net->flag_host = (int*)h;
-    void* d = nullptr;
-    IRON_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
-    net->flag_dev = (int*)d;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool_host) {
+        void* h = nullptr;
+        IRON_HIP_TRY(hipHostMalloc(&h, (size_t)kPoolSlots * kSlotInts * sizeof(int), hipHostMallocMapped));
+        void* d = nullptr;
+        IRON_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+        memset(h, 0, (size_t)kPoolSlots * kSlotInts * sizeof(int));
+        g_pool_host = (int*)h;
+        g_pool_dev = (int*)d;
+        g_pool_free.reserve(kPoolSlots);
+        for (int i = kPoolSlots - 1; i >= 0; --i) g_pool_free.push_back(i);
+    }
+    if (g_pool_free.empty()) { net->flag_host = net->flag_dev = nullptr; return IRON_OK; }   // > 4096 live handles: unguarded, not an error
+    const int slot = g_pool_free.back();
+    g_pool_free.pop_back();
+    net->flag_host = g_pool_host + (size_t)slot * kSlotInts;
+    net->flag_dev = g_pool_dev + (size_t)slot * kSlotInts;
+    *(volatile int*)net->flag_host = 0;
     return IRON_OK;
 }
 
 void envelope_destroy(iron_net* net) {
-    if (net->flag_host) (void)hipHostFree(net->flag_host);
+    if (net->flag_host) {
+        // a scan kernel of this handle may still be in flight: its (rare) write lands in a slot that is zeroed again when it is handed out
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool_free.push_back((int)((net->flag_host - g_pool_host) / kSlotInts));
+    }
     net->flag_host = net->flag_dev = nullptr;
 }
 
