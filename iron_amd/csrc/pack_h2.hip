@@ -23,7 +23,10 @@ __device__ __forceinline__ void store_split(_Float16* dst_hi, _Float16* dst_lo, 
 }
 
 // dst: one hidden slot (32 KiB): fragments [ks 0..15][piece 0..1][lane 64][j 8] of fp16
-__global__ void k_pack_h2_hidden(_Float16* __restrict__ dst, PackSrc s, int to, int col_off, int cols_valid) {
+// (all slot packers: blockIdx.y = tile offset within a run of equally spaced slots; dst / to are the run's first slot / tile)
+__global__ void k_pack_h2_hidden(_Float16* __restrict__ dst, size_t stride, PackSrc s, int to, int col_off, int cols_valid) {
+    dst = (_Float16*)((char*)dst + blockIdx.y * stride);
+    to += blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
     if (e >= 16 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -38,7 +41,9 @@ __global__ void k_pack_h2_hidden(_Float16* __restrict__ dst, PackSrc s, int to, 
 
 // dst: one head slot (8 KiB): fragments [ks 0..2][piece][lane][j] + 2 KiB of zero padding
 // slot_off: first head slot of this ring slot (a head wider than 24 slots is streamed as two ring slots: 0 and 24)
-__global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs hs, int to, int slot_off) {
+__global__ void k_pack_h2_head(_Float16* __restrict__ dst, size_t stride, PackSrc s, HeadSrcs hs, int to, int slot_off) {
+    dst = (_Float16*)((char*)dst + blockIdx.y * stride);
+    to += blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks 0..3, lane, j)
     if (e >= 4 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -62,7 +67,9 @@ __global__ void k_pack_h2_head(_Float16* __restrict__ dst, PackSrc s, HeadSrcs h
 // Transposed hidden slot (reverse-mode get_all, mlp_h2_rev.h): output row 32*to + i of the slot is ORIGINAL COLUMN col_off + row of the
 // layer, the k index runs over the layer's original rows (its output units, in the register order their sigma' * g tiles have):
 //   dst[ks][piece][lane = (i, h)][j] = W[o][col_off + 32 to + i] * scale[o] * mul,   o = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3)
-__global__ void k_pack_h2_hidden_T(_Float16* __restrict__ dst, PackSrc s, int to, int col_off, int cols_valid) {
+__global__ void k_pack_h2_hidden_T(_Float16* __restrict__ dst, size_t stride, PackSrc s, int to, int col_off, int cols_valid) {
+    dst = (_Float16*)((char*)dst + blockIdx.y * stride);
+    to += blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
     if (e >= 16 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -78,7 +85,9 @@ __global__ void k_pack_h2_hidden_T(_Float16* __restrict__ dst, PackSrc s, int to
 // Transposed PE rows: output row i of tile T lands in accumulator register r = (i&3) + 4 (i>>3) of lane-half hh = (i>>2)&1 and stands
 // for head slot 16 T + r in the role of the OTHER half -- the row of sin(2^k v_c) goes to the half whose head slot holds cos(2^k v_c)
 // and vice versa, so that each lane contracts its rows with the PE values it already has (getall_rev.hip: pe_contract).
-__global__ void k_pack_h2_pe_T(_Float16* __restrict__ dst, PackSrc s, int T, int col_off, int levels) {
+__global__ void k_pack_h2_pe_T(_Float16* __restrict__ dst, size_t stride, PackSrc s, int T, int col_off, int levels) {
+    dst = (_Float16*)((char*)dst + blockIdx.y * stride);
+    T += blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks, lane, j)
     if (e >= 16 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -95,7 +104,9 @@ __global__ void k_pack_h2_pe_T(_Float16* __restrict__ dst, PackSrc s, int T, int
 
 // head slot of a 4-component source (NeRF background points, mlp_core.h head_fill4): slot 0 = (x|y), 1 = (z|w), then
 // (sin|cos)(2^k v_c) at slot 2 + 4k + c; embedding columns: 4 raw, then per level [sin x4 | cos x4]
-__global__ void k_pack_h2_head4(_Float16* __restrict__ dst, PackSrc s, int levels, int col_off, int to, int slot_off) {
+__global__ void k_pack_h2_head4(_Float16* __restrict__ dst, size_t stride, PackSrc s, int levels, int col_off, int to, int slot_off) {
+    dst = (_Float16*)((char*)dst + blockIdx.y * stride);
+    to += blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (ks 0..3, lane, j)
     if (e >= 4 * 64 * 8) return;
     const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
@@ -182,50 +193,57 @@ static int pack_h2_sdf_blob(iron_net* net, const iron_linear* L, const float* sc
     IRON_HIP_TRY(hipMemsetAsync(blob, 0, total, st));
     char* base = (char*)blob;
     IRON_HIP_TRY(hipMemcpyAsync(base + table_off, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    IRON_HIP_TRY(hipStreamSynchronize(st));  // `table` is host memory going out of scope
+    // (`table` lives until the synchronisation at the end of this function)
 
     HeadSrcs hs;
     memset(&hs, 0, sizeof(hs));
     hs.n = 1; hs.slot_base[0] = 0; hs.levels[0] = d.multires; hs.col_off[0] = 0;
     size_t q = 0;
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
-    for (int to = 0; to < kHidTiles; ++to, ++q)
-        hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, to, 0);
+    // one launch per run of equally spaced slots (blockIdx.y = tile): a training step re-packs every network, and one launch per slot
+    // (224 per step at C3) cost ~1 ms per step of 3-4 us launches
+    const size_t kHeadB = 8192, kHidB = kSlotBytes;
+    hipLaunchKernelGGL(k_pack_h2_head, dim3(8, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHeadB, make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), hs, 0, 0);
+    q += kHidTiles;
     for (int l = 1; l <= nl - 2; ++l) {
         const bool is_skip = (l == skip);
         const float mul = is_skip ? kInvSqrt2 : 1.0f;
         const int cols_valid = is_skip ? kHidden - pe : kHidden;
-        for (int to = 0; to < kHidTiles; ++to) {
-            if (is_skip) {
-                HeadSrcs h2 = hs;
-                h2.col_off[0] = kHidden - pe;
-                hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), h2, to, 0);
-                ++q;
-            }
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul), to, 0, cols_valid);
-            ++q;
+        const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul);
+        if (is_skip) {   // per tile: [head slot][hidden slot]
+            HeadSrcs h2 = hs;
+            h2.col_off[0] = kHidden - pe;
+            hipLaunchKernelGGL(k_pack_h2_head, dim3(8, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHeadB + kHidB, ps, h2, 0, 0);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q + 1), kHeadB + kHidB, ps, 0, 0, cols_valid);
+            q += 2 * kHidTiles;
+        } else {
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHidB, ps, 0, 0, cols_valid);
+            q += kHidTiles;
         }
     }
     const iron_linear& last = L[nl - 1];
-    if (has_feat)
-        for (int to = 0; to < kHidTiles; ++to, ++q)
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), make_pack_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), to, 0, kHidden);
+    if (has_feat) {
+        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHidB, make_pack_src(last, scale_base + soff[nl - 1], kHidden, 1, 1.0f), 0, 0, kHidden);
+        q += kHidTiles;
+    }
     if (with_rev) {
         for (int l = nl - 2; l >= 1; --l) {
             const bool is_skip = (l == skip);
             const float mul = is_skip ? kInvSqrt2 : 1.0f;
             const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], L[l].out_dim, 0, mul);
             const int cols_valid = is_skip ? kHidden - pe : kHidden;   // the layer's inputs that come from the previous layer
-            for (int to = 0; to < kHidTiles; ++to, ++q)
-                hipLaunchKernelGGL(k_pack_h2_hidden_T, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, cols_valid);
-            if (is_skip)
-                for (int T = 0; T < 2; ++T, ++q)
-                    hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, T, kHidden - pe, d.multires);
+            hipLaunchKernelGGL(k_pack_h2_hidden_T, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHidB, ps, 0, 0, cols_valid);
+            q += kHidTiles;
+            if (is_skip) {
+                hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32, 2), dim3(256), 0, st, slot_ptr(q), kHidB, ps, 0, kHidden - pe, d.multires);
+                q += 2;
+            }
         }
         const PackSrc p0 = make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f);
-        for (int T = 0; T < 2; ++T, ++q)
-            hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32), dim3(256), 0, st, slot_ptr(q), p0, T, 0, d.multires);
+        hipLaunchKernelGGL(k_pack_h2_pe_T, dim3(32, 2), dim3(256), 0, st, slot_ptr(q), kHidB, p0, 0, 0, d.multires);
+        q += 2;
     }
+    if (q != table.size() / 2) return IRON_ERR_UNSUPPORTED;   // the launches above and the slot table must describe the same sequence
     // f32 side blocks: biases of layers 0..nl-2 (+ feature bias as block nl-1), last-layer row 0
     for (int l = 0; l <= nl - 2; ++l)
         hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, L[l].out_dim);
@@ -312,31 +330,38 @@ int build_h2_render(iron_net* net, const iron_linear* L, const float* scale_base
     char* base = (char*)net->h2_blob;
     size_t q = 0;
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
+    // one launch per run of equally spaced slots (blockIdx.y = tile), as in pack_h2_sdf_blob
+    const size_t kHeadB = 8192, kHidB = kSlotBytes;
     if (skip != -1) {   // feature columns of the skip layer: [x 256 | head inputs | features 256] / sqrt(2)
         const PackSrc ps = make_pack_src(L[skip], scale_base + soff[skip], kHidden, 0, kInvSqrt2);
-        for (int to = 0; to < kHidTiles; ++to, ++q)
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, kHidden + head_w, kHidden);
+        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHidB, ps, 0, kHidden + head_w, kHidden);
+        q += kHidTiles;
     }
-    for (int to = 0; to < kHidTiles; ++to) {
+    {   // layer 0, per tile: [head slot(s)][hidden slot = feature part]
         const PackSrc ps = make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f);
-        for (int h = 0; h < n_head; ++h, ++q)
-            hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hs, to, h * kHeadSlots);
-        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, head_w, kHidden);
-        ++q;
+        const size_t stride = (size_t)n_head * kHeadB + kHidB;
+        for (int h = 0; h < n_head; ++h)
+            hipLaunchKernelGGL(k_pack_h2_head, dim3(8, kHidTiles), dim3(256), 0, st, slot_ptr(q + h), stride, ps, hs, 0, h * kHeadSlots);
+        hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q + n_head), stride, ps, 0, head_w, kHidden);
+        q += (size_t)(n_head + 1) * kHidTiles;
     }
     for (int l = 1; l <= nl - 2; ++l) {
         const bool is_skip = (l == skip);
         const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], kHidden, 0, is_skip ? kInvSqrt2 : 1.0f);
-        HeadSrcs hs2 = hs;
-        for (int k = 0; k < hs2.n; ++k) hs2.col_off[k] += kHidden;
-        for (int to = 0; to < kHidTiles; ++to) {
-            if (is_skip)
-                for (int h = 0; h < n_head; ++h, ++q)
-                    hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hs2, to, h * kHeadSlots);
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
-            ++q;
+        if (is_skip) {   // per tile: [head slot(s) of the head columns][hidden slot = the x columns]
+            HeadSrcs hs2 = hs;
+            for (int k = 0; k < hs2.n; ++k) hs2.col_off[k] += kHidden;
+            const size_t stride = (size_t)n_head * kHeadB + kHidB;
+            for (int h = 0; h < n_head; ++h)
+                hipLaunchKernelGGL(k_pack_h2_head, dim3(8, kHidTiles), dim3(256), 0, st, slot_ptr(q + h), stride, ps, hs2, 0, h * kHeadSlots);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q + n_head), stride, ps, 0, 0, kHidden);
+            q += (size_t)(n_head + 1) * kHidTiles;
+        } else {
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32, kHidTiles), dim3(256), 0, st, slot_ptr(q), kHidB, ps, 0, 0, kHidden);
+            q += kHidTiles;
         }
     }
+    if (q != table.size() / 2) return IRON_ERR_UNSUPPORTED;
     for (int l = 0; l <= nl - 2; ++l)
         hipLaunchKernelGGL(k_pack_bias, dim3(1), dim3(256), 0, st, (float*)(base + bias_off + (size_t)l * 1024), L[l].bias, 0, kHidden);
     const iron_linear& last = L[nl - 1];
@@ -401,7 +426,7 @@ int build_h2_nerf(iron_net* net, const iron_linear* L, const float* scale_base, 
     auto slot_ptr = [&](size_t idx) { return (_Float16*)(base + table[2 * idx]); };
     auto heads4 = [&](const PackSrc& ps, int to) {
         for (int h = 0; h < 2; ++h, ++q)
-            hipLaunchKernelGGL(k_pack_h2_head4, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, lp, 0, to, h * kHeadSlots);
+            hipLaunchKernelGGL(k_pack_h2_head4, dim3(8), dim3(256), 0, st, slot_ptr(q), (size_t)0, ps, lp, 0, to, h * kHeadSlots);
     };
     for (int to = 0; to < kHidTiles; ++to) heads4(make_pack_src(L[0], scale_base + soff[0], kHidden, 0, 1.0f), to);
     for (int l = 1; l < D; ++l) {
@@ -409,14 +434,14 @@ int build_h2_nerf(iron_net* net, const iron_linear* L, const float* scale_base, 
         const PackSrc ps = make_pack_src(L[l], scale_base + soff[l], kHidden, 0, 1.0f);
         for (int to = 0; to < kHidTiles; ++to) {
             if (skip_in) heads4(ps, to);
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, skip_in ? in_p : 0, kHidden);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), (size_t)0, ps, to, skip_in ? in_p : 0, kHidden);
             ++q;
         }
     }
     {
         const PackSrc ps = make_pack_src(L[D + 1], scale_base + soff[D + 1], kHidden, 0, 1.0f);
         for (int to = 0; to < kHidTiles; ++to, ++q)
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), (size_t)0, ps, to, 0, kHidden);
     }
     {
         const PackSrc ps = make_pack_src(L[D + 2], scale_base + soff[D + 2], kHidden / 2, 0, 1.0f);
@@ -424,9 +449,9 @@ int build_h2_nerf(iron_net* net, const iron_linear* L, const float* scale_base, 
         memset(&hv, 0, sizeof(hv));
         hv.n = 1; hv.slot_base[0] = 0; hv.levels[0] = lv; hv.col_off[0] = kHidden;
         for (int to = 0; to < kHidTiles / 2; ++to) {
-            hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), ps, hv, to, 0);
+            hipLaunchKernelGGL(k_pack_h2_head, dim3(8), dim3(256), 0, st, slot_ptr(q), (size_t)0, ps, hv, to, 0);
             ++q;
-            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), ps, to, 0, kHidden);
+            hipLaunchKernelGGL(k_pack_h2_hidden, dim3(32), dim3(256), 0, st, slot_ptr(q), (size_t)0, ps, to, 0, kHidden);
             ++q;
         }
     }
