@@ -116,10 +116,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
             for (int to = 0; to < kHidTiles; ++to) {
                 const f32x16 o = h2_plain_tile(ring, fb, lane, to, true, X, pb);
                 if (want_feat && !(IRON_REV_ABL & 4)) {
-                    if (dst) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[(to * 16 + r) * 64 + lane] = o[r];
-                    }
+                    if (dst) feat_store_tile(dst, to, lane, o);
 #ifdef IRON_REV_DEBUG
                     if (a.feat_rows && ok && dbg < 0) {
 #else
@@ -142,6 +139,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
             split_tile(d, Y[t]);
         }
         float gx = 0.f, gy = 0.f, gz = 0.f;
+        // the PE values the Jacobian contraction needs, once for both PE stages (20 registers live through the sweep; a second
+        // head_fill -- 18 sincosf -- cost 3.7 % of the kernel)
+        float pe[kHeadSlots];
+#pragma unroll
+        for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
+        if (!(IRON_REV_ABL & 8)) head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
         IRON_REV_DUMP(7, Y)
         h2_layer_x<kModeBwd, false, false>(ring, bias, hd, lane, Y, X, hf, pb, 6);   // W_7^T -> d_6
         IRON_REV_DUMP(6, X)
@@ -152,10 +155,6 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
         h2_layer_x<kModeBwd, false, false>(ring, bias, hd, lane, X, Y, hf, pb, 3);   // W_4[:, :217]^T -> d_3
         IRON_REV_DUMP(3, Y)
         {
-            float pe[kHeadSlots];
-#pragma unroll
-            for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
-            if (!(IRON_REV_ABL & 8)) head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
             const f32x16 g0 = h2_plain_tile(ring, bias, lane, 0, false, X, pb);      // W_4[:, 217:]^T d_4: the skip's PE rows
             pe_contract<0>(g0, pe, half, gx, gy, gz);
             const f32x16 g1 = h2_plain_tile(ring, bias, lane, 1, false, X, pb);
@@ -168,10 +167,6 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
         h2_layer_x<kModeBwd, false, false>(ring, bias, hd, lane, Y, X, hf, pb, 0);   // W_1^T -> d_0
         IRON_REV_DUMP(0, X)
         {
-            float pe[kHeadSlots];
-#pragma unroll
-            for (int i = 0; i < kHeadSlots; ++i) pe[i] = 0.0f;
-            if (!(IRON_REV_ABL & 8)) head_fill<kSdfPeLevels>(sx, sy, sz, half, pe);
             const f32x16 g0 = h2_plain_tile(ring, bias, lane, 0, false, X, pb);      // W_0^T d_0
             pe_contract<0>(g0, pe, half, gx, gy, gz);
             const f32x16 g1 = h2_plain_tile(ring, bias, lane, 1, false, X, pb);

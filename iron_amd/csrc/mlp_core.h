@@ -15,6 +15,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Packed feature tiles (what get_all hands to the material kernels through the shading workspace): per 32-point tile
+// [8 feature tiles][4 pieces][64 lanes][4 f32] -- element (t, r, lane) at ((t * 4 + r / 4) * 64 + lane) * 4 + r % 4 -- so that a lane's 16
+// registers of a tile are four 16-byte pieces and a wave's piece is 1 KiB contiguous (round 3: was [t][r][lane], sixteen dword accesses).
+__device__ __forceinline__ void feat_store_tile(float* __restrict__ tile_base, int t, int lane, const f32x16& o) {
+    float4* p = reinterpret_cast<float4*>(tile_base) + (size_t)(t * 4) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+__device__ __forceinline__ f32x16 feat_load_tile(const float* __restrict__ tile_base, int t, int lane) {
+    const float4* p = reinterpret_cast<const float4*>(tile_base) + (size_t)(t * 4) * 64 + lane;
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 x = p[q * 64];
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+    return v;
+}
+
 #ifndef IRON_WQ_DEPTH
 #define IRON_WQ_DEPTH 4  // weight fragments (pairs of 1-KiB loads) kept in flight ahead of the MFMAs
 #endif

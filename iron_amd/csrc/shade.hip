@@ -149,9 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad(SdfNetDev net, GradArgs a) 
                 if (a.feat_packed) {
                     float* dst = a.feat_packed + (size_t)tile * kSBufFloats;
 #pragma unroll
-                    for (int t = 0; t < kHidTiles; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64 + lane] = o[t][r];
+                    for (int t = 0; t < kHidTiles; ++t) feat_store_tile(dst, t, lane, o[t]);
                 }
                 if (a.feat_rows && ok) {
 #pragma unroll
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_grad_h2(H2StreamDev hs, H2Meta m
             step_hidden<kFastActS, 0>(st.rd, fb, st.wr, st.src, st.hidden, wave, lane, TO, true, in, a_hi, a_lo,        \
                                       a_hi, a_lo, dummy_out, dummy_hf);                                                 \
             const f32x16 o = h2_combine(a_hi, a_lo);                                                                    \
-            if (dst) { _Pragma("unroll") for (int r = 0; r < 16; ++r) dst[((TO) * 16 + r) * 64 + lane] = o[r]; }       \
+            if (dst) feat_store_tile(dst, TO, lane, o);                                                                \
             if (a.feat_rows && ok) {                                                                                    \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                          \
                     a.feat_rows[(size_t)li * kHidden + 32 * (TO) + (r & 3) + 8 * (r >> 2) + 4 * half] = o[r];           \
@@ -409,7 +407,7 @@ struct MatArgs {
     const float* normals;   // [*,3]   (un-normalised gradient when normalise != 0)
     const float* view;      // [*,3] or null (view = -normal when neg_normal_view != 0)
     const float* feat_rows; // [*,256] row-major or null
-    const float* feat_packed;  // [tiles][8][16][64] or null
+    const float* feat_packed;  // [tiles][8][4][64][4] (mlp_core.h: feat_load_tile) or null
     const int* list;        // index into points (hit list) or null
     const int* count_ptr;
     int count;
@@ -427,9 +425,7 @@ __device__ __forceinline__ void load_feature_tiles(const MatArgs& a, int tile, i
     if (a.feat_packed) {
         const float* src = a.feat_packed + (size_t)tile * kSBufFloats;
 #pragma unroll
-        for (int t = 0; t < kHidTiles; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] = src[(t * 16 + r) * 64 + lane];
+        for (int t = 0; t < kHidTiles; ++t) h[t] = feat_load_tile(src, t, lane);
     } else {
         const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
 #pragma unroll
@@ -573,8 +569,7 @@ __global__ __launch_bounds__(256, 1) void k_material_h2(H2StreamDev hs, RenderNe
             for (int t = 0; t < kHidTiles; ++t) {
                 f32x16 v = zero16();
                 if (src) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = src[(t * 16 + r) * 64 + lane];
+                    v = feat_load_tile(src, t, lane);
                 } else if (a.feat_rows && ok) {
                     const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
 #pragma unroll
@@ -665,8 +660,7 @@ __global__ __launch_bounds__(256, 1) void k_material_h2_skip(H2StreamDev hs, Ren
             for (int t = 0; t < kHidTiles; ++t) {
                 f32x16 v = zero16();
                 if (src) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = src[(t * 16 + r) * 64 + lane];
+                    v = feat_load_tile(src, t, lane);
                 } else if (a.feat_rows && ok) {
                     const float4* row = reinterpret_cast<const float4*>(a.feat_rows + (size_t)ai * kHidden);
 #pragma unroll

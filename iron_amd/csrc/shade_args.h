@@ -9,7 +9,7 @@ struct GradArgs {
     const int* list;       // hit list (indices into x) or null = identity
     const int* count_ptr;  // device count or null
     int count;             // used when count_ptr == null
-    float* feat_packed;    // [tiles][8][16][64] or null
+    float* feat_packed;    // [tiles][8][4][64][4] (mlp_core.h: feat_store_tile) or null
     float* sdf_out;        // [count] (list order) or null
     float* grad_out;       // [count,3] (list order) or null
     float* feat_rows;      // [count,256] row-major or null
