@@ -30,6 +30,9 @@ __device__ __forceinline__ void pe_contract(const f32x16& g, const float* pe, in
     }
 }
 
+#ifndef IRON_REV_FEAT_NT
+#define IRON_REV_FEAT_NT 0
+#endif
 #ifdef IRON_REV_DEBUG   // diagnostic build (tools/diag_getall_rev.py): feat_rows receives d_l = d sdf / d z_l of layer `dbg` instead of the features
 #define IRON_REV_DUMP(L, BUF)                                                                                              \
     if (dbg == (L) && a.feat_rows && ok) {                                                                                 \
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_getall_rev_h2(H2StreamDev hs, H2
             for (int to = 0; to < kHidTiles; ++to) {
                 const f32x16 o = h2_plain_tile(ring, fb, lane, to, true, X, pb);
                 if (want_feat && !(IRON_REV_ABL & 4)) {
-                    if (dst) feat_store_tile(dst, to, lane, o);
+                    if (dst) feat_store_tile<IRON_REV_FEAT_NT != 0>(dst, to, lane, o);
 #ifdef IRON_REV_DEBUG
                     if (a.feat_rows && ok && dbg < 0) {
 #else

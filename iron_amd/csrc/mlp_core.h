@@ -18,10 +18,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // Packed feature tiles (what get_all hands to the material kernels through the shading workspace): per 32-point tile
 // [8 feature tiles][4 pieces][64 lanes][4 f32] -- element (t, r, lane) at ((t * 4 + r / 4) * 64 + lane) * 4 + r % 4 -- so that a lane's 16
 // registers of a tile are four 16-byte pieces and a wave's piece is 1 KiB contiguous (round 3: was [t][r][lane], sixteen dword accesses).
+template <bool NT = false>
 __device__ __forceinline__ void feat_store_tile(float* __restrict__ tile_base, int t, int lane, const f32x16& o) {
-    float4* p = reinterpret_cast<float4*>(tile_base) + (size_t)(t * 4) * 64 + lane;
+    f32x4* p = reinterpret_cast<f32x4*>(tile_base) + (size_t)(t * 4) * 64 + lane;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = o[4 * q]; v[1] = o[4 * q + 1]; v[2] = o[4 * q + 2]; v[3] = o[4 * q + 3];
+        if (NT) __builtin_nontemporal_store(v, p + q * 64);   // read once, by a later kernel
+        else p[q * 64] = v;
+    }
 }
 __device__ __forceinline__ f32x16 feat_load_tile(const float* __restrict__ tile_base, int t, int lane) {
     const float4* p = reinterpret_cast<const float4*>(tile_base) + (size_t)(t * 4) * 64 + lane;

@@ -31,6 +31,11 @@ struct ParkBuf {
 
 __device__ __forceinline__ int park_off(int layer, int tile, int wave) { return ((layer * kHidTiles + tile) * 4 + wave) * kParkTileBytes; }
 
+#ifndef IRON_REV_TAPE_AUX
+#define IRON_REV_TAPE_AUX 2   // cache policy bits of the tape's buffer stores / loads: 2 = nt.  The tape is written once and read once, 80+ ring
+                              // steps later, by the same lane: with the default policy its 1 MiB per workgroup pass washes the weight stream's
+                              // slots out of L2 (4.61 ms per 524 288 points; nt 4.08; sc0 alone 4.61)
+#endif
 #ifndef IRON_REV_ABL
 #define IRON_REV_ABL 0   // timing ablations (garbage results): 1 no tape stores, 2 no tape loads, 4 no feature stores, 8 no PE recompute
 #endif
@@ -43,7 +48,7 @@ __device__ __forceinline__ void park_store_piece(const ParkBuf& pb, int off, int
     u32x4 v;
     v[0] = __builtin_bit_cast(unsigned, a); v[1] = __builtin_bit_cast(unsigned, b);
     v[2] = __builtin_bit_cast(unsigned, c); v[3] = __builtin_bit_cast(unsigned, d);
-    __builtin_amdgcn_raw_buffer_store_b128(v, pb.rsrc, pb.voff + piece * 1024, off, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, pb.rsrc, pb.voff + piece * 1024, off, IRON_REV_TAPE_AUX);
 }
 
 __device__ __forceinline__ void park_store_tile(const ParkBuf& pb, int off, const f32x16& p) {
@@ -61,7 +66,7 @@ __device__ __forceinline__ f32x16 park_load_tile(const ParkBuf& pb, int off) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // (bit_cast of the builtin's result, as in mlp_core.h: assigning it to an ext_vector_type makes hipcc 7.2 load ONE dword and splat it)
-        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pb.rsrc, pb.voff + q * 1024, off, 0));
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pb.rsrc, pb.voff + q * 1024, off, IRON_REV_TAPE_AUX));
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[4 * q + i] = v[i];
     }
