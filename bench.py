@@ -382,7 +382,7 @@ def cpu_baseline(scene: str, res: int):
             "host": host}
 
 
-def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=4):
+def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps=3):
     """One-GPU PREDICTION for the multi-GPU target (no collectives in it): for world = 2, 4, 8 every rank's tile shard of the frame is
     run on this card the way the rank runs it -- its rank-local phases of ShardedRenderer (trace_begin -> trace_finish -> shade) back
     to back, `steps` steps without a host sync in between -- and T(frame) / max_r T(rank r step) is the strong-scaling factor the
@@ -394,15 +394,25 @@ def predicted_strong_scaling(cam, sdf, nets, fn, tracer_factory, frame_ms, steps
                    "no collectives); factor_with_assemble adds rank 0's un-tile"}
     for world in (2, 4, 8):
         ms = []
+        shs = [ShardedRenderer(sdf, nets, tracer_factory(), fn, tile=SHARD_TILE, chunk=50000, world=world, rank=r) for r in range(world)]
+        # the chunk-global bisection counts after the MAX all-reduce: every rank runs its second tracer phase up to the SAME counts
+        # (one rank's own table would let seven of eight ranks off ~0.4 ms of dependent evaluations)
+        table = None
+        for sh in shs:
+            st = sh.trace_begin([cam])
+            table = st["chunk_iters"].clone() if table is None else torch.maximum(table, st["chunk_iters"])
+            sh.trace_finish(st)
         for r in range(world):
-            sh = ShardedRenderer(sdf, nets, tracer_factory(), fn, tile=SHARD_TILE, chunk=50000, world=world, rank=r)
+            sh = shs[r]
 
             def step():
-                return sh.shade(sh.trace_finish(sh.trace_begin([cam])))
-            for _ in range(2):
+                st = sh.trace_begin([cam])
+                st["chunk_iters"].copy_(table)
+                return sh.shade(sh.trace_finish(st))
+            for _ in range(4):
                 step()
             best = None
-            for _ in range(3):   # best of 3 runs of `steps` steps: a caching-allocator stall (new 256 MiB blocks) inflates single runs 2x
+            for _ in range(5):   # best of 5 runs of `steps` steps: a caching-allocator stall (new 256 MiB blocks) inflates single runs 2x
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):

@@ -286,3 +286,27 @@ def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise IronError("%s must be float32, got %s" % (name, t.dtype))
     return t.contiguous()
+
+
+# ---- call-scoped workspaces ----------------------------------------------------------------------------------------------------
+# Several entries take a caller-owned workspace whose contents mean nothing once the call's kernels have run (the tape of the
+# reverse-mode get_all: 1 MiB per resident workgroup, the shading workspace, the single-call tracer's lists).  A fresh torch.empty
+# per call goes through the caching allocator, which now and then answers a 256 MiB request with a hipFree / hipMalloc pair --
+# a device synchronisation in the middle of a frame (C2 ran 9.8 or 17.6 ms per batch depending on it).  One growing buffer per
+# (device, stream, purpose) instead: calls on one stream are ordered, so the next call may overwrite it.
+_workspaces = {}
+
+
+def workspace(nbytes: int, device, tag: str):
+    """A uint8 CUDA buffer of at least `nbytes` (>= 16) for the CURRENT stream of `device`, valid until the next workspace() call
+    with the same tag on that stream."""
+    import torch
+    nbytes = max(int(nbytes), 16)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _workspaces.pop(key, None)
+        buf = torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

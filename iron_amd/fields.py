@@ -303,7 +303,7 @@ def _get_all_workspace(net, n, device):
     nbytes = int(_lib.load().iron_sdf_get_all_workspace_bytes(net.handle, n))
     if nbytes == 0:
         return None, 0
-    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+    return _lib.workspace(nbytes, device, "get_all"), nbytes
 
 
 # IDR-style material MLP (reference: models/fields.py:141-239)

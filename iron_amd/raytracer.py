@@ -125,7 +125,7 @@ class RayTracer(nn.Module):
         lib = _lib.load()
         prm = self._params(chunk)
         ws_bytes = lib.iron_trace_workspace_bytes(n, C.byref(prm))
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(ws_bytes, dev, "trace")
         stats = torch.zeros(8, dtype=torch.int64, device=dev) if collect_stats else None
         lin = _linspace_steps(self.n_steps, dev)
         with torch.cuda.device(dev):
@@ -160,7 +160,7 @@ class RayTracer(nn.Module):
             lib = _lib.load()
             prm = self._params(0)
             ws_bytes = lib.iron_trace_workspace_bytes(n, C.byref(prm))
-            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            ws = _lib.workspace(ws_bytes, dev, "trace")
             lin = _linspace_steps(self.n_steps, dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.iron_trace_stage(stage, net.hip_net().handle, C.byref(prm), lin.data_ptr(), o.data_ptr(), d.data_ptr(),

@@ -147,7 +147,7 @@ class CompRenderFn:
             setattr(so, k, bufs[k].data_ptr())
         t1, t2 = self.renderer._tables_on(dev)
         ws_bytes = lib.iron_shade_composite_workspace_bytes(n)
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(ws_bytes, dev, "shade")
         light = _host_light(color_network_dict["point_light_network"])
         with torch.cuda.device(dev):
             _lib.check(lib.iron_shade_composite(C.byref(nets), light, t1.data_ptr(), t2.data_ptr(), ray_o.data_ptr(), ray_d.data_ptr(),
@@ -217,7 +217,7 @@ class GGXRenderFn:
             setattr(so, k, bufs[k].data_ptr())
         t1, t2 = self.renderer._tables_on(dev)
         ws_bytes = lib.iron_shade_workspace_bytes(n)
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(ws_bytes, dev, "shade")
         light = _host_light(color_network_dict["point_light_network"])
         with torch.cuda.device(dev):
             _lib.check(lib.iron_shade_ggx(C.byref(nets), light, 1 if self.is_metal else 0, t1.data_ptr(), t2.data_ptr(),

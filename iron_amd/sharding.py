@@ -27,10 +27,13 @@ RECORD_WIDTH = sum(w for _, w in RECORD)
 
 def tile_pixels(H: int, W: int, tile: int, world: int, rank: int) -> torch.Tensor:
     """Flat pixel indices (row-major, int64) of the tiles owned by `rank`: tiles are numbered row-major and
-    dealt round-robin; pixels inside a tile stay row-major."""
+    dealt on a skewed lattice (below); pixels inside a tile stay row-major."""
     ty, tx = (H + tile - 1) // tile, (W + tile - 1) // tile
     ids = torch.arange(ty * tx, dtype=torch.int64)
-    mine = ids[ids % world == rank]
+    # owner of tile (row, col) = (col + skew * row) % world: a diagonal lattice with `world` distinct row phases.  Plain tile_id % world
+    # degenerates when the tiles per row share a factor with `world` (100 tiles per row over 8 ranks: only two row phases, i.e. vertical
+    # stripes that line up with the silhouette -- one rank 6 % above the others at 800 x 800)
+    mine = ids[((ids % tx) + _skew(world) * (ids // tx)) % world == rank]
     r0 = (mine // tx) * tile
     c0 = (mine % tx) * tile
     dy = torch.arange(tile, dtype=torch.int64).view(1, tile, 1)
@@ -39,6 +42,15 @@ def tile_pixels(H: int, W: int, tile: int, world: int, rank: int) -> torch.Tenso
     cols = c0.view(-1, 1, 1) + dx
     ok = (rows < H) & (cols < W)
     return (rows * W + cols)[ok]
+
+
+def _skew(world: int) -> int:
+    """Row-to-row shift of the tile lattice: the integer nearest 0.382 x world (golden-section spacing) that is coprime to `world`."""
+    import math
+    s = max(1, round(0.382 * world))
+    while math.gcd(s, world) != 1:
+        s += 1
+    return s
 
 
 def shard_sizes(H: int, W: int, tile: int, world: int) -> List[int]:
