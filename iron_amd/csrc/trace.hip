@@ -47,7 +47,8 @@ struct TraceCounters {  // zeroed at the start of every call
     int n_root;         // rays with a sign-change bracket
     int root_head_a;
     int root_head_b;
-    int pad[2];
+    int n_cont;         // k_sampler: continuation items published
+    int n_sampler_done; // k_sampler: listed rays whose sampling has ended
     long long n_evals;
     long long n_sphere_conv;
     long long n_evals_sphere;
@@ -66,6 +67,8 @@ struct TraceWs {
     int* chunk_iters;   // [n_chunks]
     int* chunk_roots;   // [n_chunks] bisected rays per chunk (for the reference-equivalent eval count)
     int n_chunks;
+    unsigned long long* cont;  // k_sampler's continuation items, [cont_cap] (zeroed at the start of a call)
+    int cont_cap;
 };
 
 struct TraceArgs {
@@ -243,15 +246,43 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sphere(IRON_TRACE_KERNEL_AR
 
 // Samples of one ray evaluated per pass.  A wave's 32 points per pass are 32 / kSamplerBlock rays ("slots"), each marching
 // through its n_steps samples kSamplerBlock at a time and leaving at the first block that holds a negative sample; a finished
-// slot is refilled from the list at once.  The reference evaluates all n_steps samples of every listed ray
+// slot is refilled at once.  The reference evaluates all n_steps samples of every listed ray
 // (raytracer.py:153-166); the finer the block, the fewer evaluations behind the first sign change are executed (block 32:
 // 77 of 128 on average at 800x800 S0; block 8: 65) -- the samples that ARE evaluated, and what is made of them, are the same.
+//
+// Work items and the drain (round 3).  A listed ray needs 1 .. n_steps / kSamplerBlock passes, which nobody knows in advance: when the
+// list ran out, every workgroup sat on a few long rays (up to 16 passes of 84 us each at 4 slots per wave) while the rest of its
+// lanes -- and, a little later, most of the chip -- had nothing to pull.  Now a ray is marched kSamplerSeg blocks at a time: a slot
+// that reaches a segment's end without a negative sample PUBLISHES the rest of the ray as a new item (ray, next block, f of the last
+// sample: one 64-bit word) behind the list and takes the next ticket like any free slot.  Items = the list's rays (tickets below
+// n_list) followed by the continuations in publication order; a ticket beyond what has been published is held and polled once per
+// pass.  The march order of a ray's samples, the samples evaluated and the outcome are those of the one-slot-per-ray form; only which
+// slot of which workgroup evaluates a segment changes.  The kernel ends when every listed ray has ended (n_sampler_done == n_list);
+// no workgroup waits on another's arrival -- every published item has exactly one ticket, held by a running wave or not yet drawn --
+// so a grid that is not fully resident cannot deadlock.  Relaxed agent-scope atomics on the 64-bit word are all the ordering it needs
+// (everything else an item refers to was written before the kernel started).
 #ifndef IRON_SAMPLER_BLOCK
 #define IRON_SAMPLER_BLOCK 8
 #endif
+#ifndef IRON_SAMPLER_SEG
+#define IRON_SAMPLER_SEG 4   // blocks per work item; 0: a slot keeps its ray to the end (the round-2 form)
+#endif
 constexpr int kSamplerBlock = IRON_SAMPLER_BLOCK;
 constexpr int kSamplerSlots = 32 / kSamplerBlock;
+constexpr int kSamplerSeg = IRON_SAMPLER_SEG;
 static_assert(kSamplerBlock == 4 || kSamplerBlock == 8 || kSamplerBlock == 16 || kSamplerBlock == 32, "sampler block");
+constexpr int kContRayBits = 24, kContBlkBits = 8;   // item word: [ray + 1 : 24][next block : 8][f of the previous sample : 32]
+
+// continuation items a call of n rays can publish (0: the kernel keeps every ray in its slot)
+static inline int64_t sampler_cont_cap(int64_t n, int n_steps) {
+    if (kSamplerSeg <= 0) return 0;
+    const int64_t blocks = (n_steps + kSamplerBlock - 1) / kSamplerBlock;
+    if (n + 2 >= (1ll << kContRayBits) || blocks >= (1ll << kContBlkBits)) return 0;
+    const int64_t segs = (blocks + kSamplerSeg - 1) / kSamplerSeg;
+    return n * (segs - 1);
+}
+
+__device__ __forceinline__ float sample_depth(float smin, float lin, float width) { return smin + lin * width; }   // raytracer.py:147-149
 
 template <class BE>
 __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_ARGS) {
@@ -263,26 +294,64 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
     const int slot_lane0 = slot * kSamplerBlock;
     const unsigned slot_bits = (kSamplerBlock == 32 ? 0xffffffffu : ((1u << kSamplerBlock) - 1u)) << slot_lane0;
     const int n_list = w.cnt->n_sampler;
+    const bool dyn = w.cont_cap > 0;
+    const long long n_tickets = (long long)n_list + (dyn ? (long long)w.cont_cap : 0ll);
     long long evals = 0;
-    bool has_ray = false, exhausted = false;   // has_ray: uniform over the lanes of a slot
+    // per slot (uniform over its lanes): a ray, or a ticket for the next item, or nothing more to draw
+    bool has_ray = false, retired = false, publish = false;
+    int ticket = -1;
     int ray = 0, blk = 0;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, smin = 0.f, width = 0.f, prev_z = 0.f, prev_f = 0.f;
+    unsigned idle_polls = 0;
     for (;;) {
-        // ---- refill the free slots: one atomicAdd per wave for all of them
-        const unsigned busy = (unsigned)__ballot(has_ray);   // lower 32 bits: lanes 0..31
-        unsigned free_slots = 0;
+        // ---- publish the continuations of the last pass and draw tickets for the free slots: one atomicAdd each per wave
+        unsigned pub_slots = 0, need_slots = 0;
+        {
+            const unsigned pub = (unsigned)__ballot(publish), need = (unsigned)__ballot(!has_ray && ticket < 0 && !retired);
 #pragma unroll
-        for (int q = 0; q < kSamplerSlots; ++q) free_slots |= ((busy >> (q * kSamplerBlock)) & 1u) ? 0u : (1u << q);
-        if (free_slots && !exhausted) {
-            const int nfree = __popc(free_slots);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&w.cnt->sampler_head, nfree);
-            base = __shfl(base, 0, 64);
-            if (base + nfree >= n_list) exhausted = true;
-            const int rank = __popc(free_slots & ((1u << slot) - 1u));
-            const int i = base + rank;
-            if (!has_ray && i < n_list) {
-                ray = w.sampler_list[i];
+            for (int q = 0; q < kSamplerSlots; ++q) {
+                pub_slots |= ((pub >> (q * kSamplerBlock)) & 1u) << q;
+                need_slots |= ((need >> (q * kSamplerBlock)) & 1u) << q;
+            }
+        }
+        if (pub_slots | need_slots) {
+            int v = 0;
+            if (lane == 0 && need_slots) v = atomicAdd(&w.cnt->sampler_head, __popc(need_slots));
+            if (lane == 1 && pub_slots) v = atomicAdd(&w.cnt->n_cont, __popc(pub_slots));
+            const int tbase = __shfl(v, 0, 64), pbase = __shfl(v, 1, 64);
+            if (publish) {
+                const int c = pbase + __popc(pub_slots & ((1u << slot) - 1u));
+                if (lane == slot_lane0 && c < w.cont_cap) {
+                    const unsigned long long item = (unsigned long long)(unsigned)(ray + 1) | ((unsigned long long)(unsigned)blk << kContRayBits) |
+                                                    ((unsigned long long)__float_as_uint(prev_f) << 32);
+                    __hip_atomic_store(&w.cont[c], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                publish = false;
+            }
+            if (!has_ray && ticket < 0 && !retired) {
+                const long long t = (long long)tbase + __popc(need_slots & ((1u << slot) - 1u));
+                if (t >= n_tickets || tbase < 0) retired = true;   // nothing beyond: every ray publishes at most segs - 1 items
+                else ticket = (int)t;
+            }
+        }
+        // ---- a held ticket: the list's ray, or the continuation item once it is there
+        if (!has_ray && ticket >= 0) {
+            bool got = false;
+            if (ticket < n_list) {
+                ray = w.sampler_list[ticket];
+                blk = 0;
+                prev_f = 0.f;
+                got = true;
+            } else {
+                const unsigned long long item = __hip_atomic_load(&w.cont[ticket - n_list], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (item != 0ull) {
+                    ray = (int)(item & ((1u << kContRayBits) - 1u)) - 1;
+                    blk = (int)((item >> kContRayBits) & ((1u << kContBlkBits) - 1u));
+                    prev_f = __uint_as_float((unsigned)(item >> 32));
+                    got = true;
+                }
+            }
+            if (got) {
                 ox = a.ray_o[3 * (size_t)ray]; oy = a.ray_o[3 * (size_t)ray + 1]; oz = a.ray_o[3 * (size_t)ray + 2];
                 dx = a.ray_d[3 * (size_t)ray]; dy = a.ray_d[3 * (size_t)ray + 1]; dz = a.ray_d[3 * (size_t)ray + 2];
                 const float t = a.dist[ray], s0 = a.sdf[ray];
@@ -290,15 +359,22 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
                 smin = pos ? t : a.near[ray];
                 const float smax = pos ? a.far[ray] : t;
                 width = smax - smin;
-                blk = 0;
-                prev_z = prev_f = 0.f;
+                prev_z = blk > 0 ? sample_depth(smin, a.lin[blk * kSamplerBlock - 1], width) : 0.f;   // the sample before the item's first
                 has_ray = true;
+                ticket = -1;
             }
         }
-        if (!be.any(__ballot(has_ray) != 0ull)) break;
+        if (!be.any(__ballot(has_ray) != 0ull)) {
+            // no ray in the workgroup: done when no slot holds a ticket that can still be served
+            const bool all_ended = __hip_atomic_load(&w.cnt->n_sampler_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_list;
+            const bool waiting = __ballot(ticket >= 0 || publish) != 0ull && !all_ended;
+            if (!be.any(waiting) || ++idle_polls > (1u << 22)) break;   // (the bound: a few seconds; never reached unless the protocol is broken)
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
         const int idx = blk * kSamplerBlock + s_in;
         const bool in_range = has_ray && idx < a.n_steps;
-        const float z = smin + a.lin[in_range ? idx : a.n_steps - 1] * width;                      // raytracer.py:147-149
+        const float z = sample_depth(smin, a.lin[in_range ? idx : a.n_steps - 1], width);
         const float qx = has_ray ? ox + dx * z : 0.f, qy = has_ray ? oy + dy * z : 0.f, qz = has_ray ? oz + dz * z : 0.f;  // :150
         const float f = be.eval(qx, qy, qz);
         evals += __popc((unsigned)__ballot(in_range));   // lanes 32..63 mirror 0..31: the low word counts every point once
@@ -328,11 +404,15 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
                 a.sdf[ray] = 0.f;
                 a.dist[ray] = 0.f;
             }
+            atomicAdd(&w.cnt->n_sampler_done, 1);
         }
         prev_z = z_last;
         prev_f = f_last;
         ++blk;
-        if (done) has_ray = false;
+        // the end of a work item: the ray goes back to the queue (published at the top of the next pass), the slot draws the next ticket
+        const bool hand_over = has_ray && !done && dyn && (blk % (kSamplerSeg > 0 ? kSamplerSeg : 1)) == 0;
+        publish = hand_over;
+        if (done || hand_over) has_ray = false;
     }
     be.finish();
     if (lane == 0) atomicAdd((unsigned long long*)&w.cnt->n_evals, (unsigned long long)evals);
@@ -526,8 +606,8 @@ __global__ void k_stage_root_init(TraceWs w, int n, const float* __restrict__ f_
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t cnt, sampler_list, root_list, lo, hi, flo, fhi, k, chunk_iters, chunk_roots, total;
-    int64_t n_chunks;
+    size_t cnt, sampler_list, root_list, lo, hi, flo, fhi, k, chunk_iters, chunk_roots, cont, total;
+    int64_t n_chunks, cont_cap;
 };
 
 static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
@@ -547,6 +627,8 @@ static WsLayout ws_layout(int64_t n, const iron_trace_params* p) {
     L.flo = o; o += align256(sizeof(float) * nn);
     L.fhi = o; o += align256(sizeof(float) * nn);
     L.k = o; o += align256(sizeof(int) * nn);
+    L.cont_cap = sampler_cont_cap(n, p ? p->n_steps : 128);   // k_sampler's continuation items
+    L.cont = o; o += align256(sizeof(unsigned long long) * (size_t)(L.cont_cap > 0 ? L.cont_cap : 1));
     L.total = o;
     return L;
 }
@@ -688,6 +770,8 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
     w0.chunk_iters = chunk_iters ? chunk_iters : (int*)(base + L.chunk_iters);
     w0.chunk_roots = (int*)(base + L.chunk_roots);
     w0.n_chunks = (int)(chunk_iters ? n_chunks : L.n_chunks);
+    w0.cont = (unsigned long long*)(base + L.cont);
+    w0.cont_cap = (int)L.cont_cap;
     if (chunk_iters && n_chunks > L.n_chunks) {
         // multi-rank: the chunk table covers the whole image, not just this rank's rays
         if (workspace_bytes < L.total + align256(sizeof(int) * (size_t)n_chunks)) return IRON_ERR_WORKSPACE;
@@ -723,6 +807,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         if (chunk_iters) IRON_HIP_TRY(hipMemsetAsync(chunk_iters, 0, sizeof(int) * (size_t)n_chunks, st));
         else IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int) * (size_t)L.n_chunks), st));
         IRON_HIP_TRY(hipMemsetAsync(w0.chunk_roots, 0, sizeof(int) * (size_t)w0.n_chunks, st));
+        if (L.cont_cap > 0) IRON_HIP_TRY(hipMemsetAsync(base + L.cont, 0, sizeof(unsigned long long) * (size_t)L.cont_cap, st));
     }
     if (parts > 1) IRON_HIP_TRY(hipEventRecord(S->fork, st));
     // side parts first: their launches are queued before the caller-stream part occupies the chip
@@ -736,6 +821,7 @@ extern "C" int iron_trace_phase(int32_t phase, const iron_net_t* sdf, const iron
         w.cnt = (TraceCounters*)(base + L.cnt + (size_t)k * kCntStride);
         w.sampler_list += b0; w.root_list += b0; w.root_lo += b0; w.root_hi += b0; w.root_flo += b0; w.root_fhi += b0; w.root_k += b0;
         a.ray0 = (int)b0; a.n = (int)nk;
+        if (L.cont_cap > 0) { const int64_t per_ray = L.cont_cap / n; w.cont += b0 * per_ray; w.cont_cap = (int)(nk * per_ray); }
         const int64_t tiles = (nk + 31) / 32;
         if (phase == 0) {
             {
@@ -793,6 +879,8 @@ extern "C" int iron_trace_stage(int32_t stage, const iron_net_t* sdf, const iron
     w.chunk_iters = (int*)(base + L.chunk_iters);
     w.chunk_roots = (int*)(base + L.chunk_roots);
     w.n_chunks = 1;
+    w.cont = (unsigned long long*)(base + L.cont);
+    w.cont_cap = (int)L.cont_cap;
     TraceArgs a;
     a.ray_o = ray_o; a.ray_d = ray_d; a.work = work; a.ray_index = nullptr; a.lin = lin_steps;
     a.conv = mask_out; a.points = points; a.sdf = sdf_out; a.dist = dist;
@@ -802,6 +890,7 @@ extern "C" int iron_trace_stage(int32_t stage, const iron_net_t* sdf, const iron
     IRON_HIP_TRY(hipMemsetAsync(base + L.cnt, 0, kCntStride * kMaxTraceSplits, st));
     IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_iters, 0, align256(sizeof(int)), st));
     IRON_HIP_TRY(hipMemsetAsync(base + L.chunk_roots, 0, align256(sizeof(int)), st));
+    if (L.cont_cap > 0) IRON_HIP_TRY(hipMemsetAsync(base + L.cont, 0, sizeof(unsigned long long) * (size_t)L.cont_cap, st));
     const int64_t tiles = (n + 31) / 32;
     const unsigned gb = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     if (stage == 0) {            // sphere_tracing (raytracer.py:105-140): in0 = min_dis, in1 = max_dis
