@@ -176,6 +176,15 @@ size_t iron_train_gemm_workspace_bytes(int32_t op_a, int32_t m, int32_t n);
 int iron_train_gemm(int32_t op_a, int32_t op_b, int32_t m, int32_t n, int32_t k, const float* A, int32_t lda, const float* B, int32_t ldb,
                     float beta, float* C, int32_t ldc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Operand range of the backward passes.  Their layer products split every fp32 operand into two fp16 pieces (csrc/gemm_h2.h); a
+ * gradient operand is scaled by a power of two from its absolute maximum first, the other operands (activations, tangent rows,
+ * weights) are split as they are, so an element beyond fp16's largest number (|x| > 65 504) or a non-finite one yields inf / NaN
+ * gradients where the reference's fp32 autograd (render_surface.py:533-653) has ordinary numbers.  Every splitting kernel raises
+ * a sticky device flag when it meets such an element; this call synchronises `stream` and returns IRON_ERR_RANGE if the flag is
+ * up (and lowers it when `reset` is non-zero), IRON_OK otherwise.  The networks of the reference's scenes stay far inside the
+ * range (weight_g up to 137, pre-activations about 10). */
+int iron_train_numeric_status(int32_t reset, void* stream);
+
 /* Diagnostics: last hipError_t seen by this library on the calling thread (iron_train_last_blas_status: kept for ABI
  * stability, always 0: the library links no BLAS). */
 int iron_train_last_hip_error(void);

@@ -193,6 +193,7 @@ TRAIN_SYMBOLS = {
     "iron_neus_composite_backward": (C.c_int, [C.POINTER(iron_neus_composite_args), C.POINTER(iron_neus_composite_grads), _P]),
     "iron_train_last_hip_error": (C.c_int, []),
     "iron_train_last_blas_status": (C.c_int, []),
+    "iron_train_numeric_status": (C.c_int, [_I32, _P]),
 }
 
 _lock = threading.Lock()

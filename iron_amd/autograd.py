@@ -505,6 +505,18 @@ class NeusCompositeFn(torch.autograd.Function):
                 d_bgd.reshape(s_bgd) if bg else None, d_bgc.reshape(s_bgc) if bg else None, None, None, None, None, None, None)
 
 
+def numeric_status(reset: bool = True, device=None) -> bool:
+    """True when a backward pass since the last reset met an operand outside the range of its split-fp16 layer products
+    (|x| > 65 504 or non-finite: the gradients of that pass are inf / NaN where fp32 autograd has numbers; include/iron_train.h).
+    Synchronises the current stream of `device`."""
+    lib = _lib.load_train()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    rc = lib.iron_train_numeric_status(1 if reset else 0, _lib.stream_ptr(dev))
+    if rc not in (0, -6):
+        raise _lib.IronError("iron_train_numeric_status failed (%d)" % rc)
+    return rc == -6
+
+
 def any_requires_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
 

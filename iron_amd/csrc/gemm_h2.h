@@ -59,8 +59,16 @@ __device__ __forceinline__ float gemm_scale_for(float amax) {
     return ldexpf(1.0f, 14 - e);
 }
 
-// 8 fp32 -> 8 fp16 high pieces + 8 fp16 low pieces (both round to nearest; x - f32(hi) is exact)
-__device__ __forceinline__ void gemm_split8(const float* v, g_u32x4& hi, g_u32x4& lo) {
+// Range of the split: an operand element beyond fp16's largest number (65 504, after the gradient operand's power-of-two scale)
+// or a non-finite one has no fp16 high piece -- the product would come out inf / NaN where the reference's fp32 arithmetic has
+// an ordinary number.  Every kernel that splits an operand raises this sticky flag (one comparison per element, off the HBM-bound
+// path); iron_train_numeric_status reads it.
+__device__ int g_gemm_range_flag = 0;
+
+// 8 fp32 -> 8 fp16 high pieces + 8 fp16 low pieces (both round to nearest; x - f32(hi) is exact); bad |= any element out of range
+__device__ __forceinline__ void gemm_split8(const float* v, g_u32x4& hi, g_u32x4& lo, unsigned& bad) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.0f) ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         g_half2 h, l;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_f16(GemmArgs g) {   // <=
             for (int r = 0; r < 16; ++r) { acc_hi[i][j][r] = 0.0f; acc_lo[i][j][r] = 0.0f; }
 
     float v[4][8];
+    unsigned bad = 0;
     auto fetch = [&](int kbase) {
         if (loads_a) la.load(w, kbase, k_end, a_scale, v);
         else lb.load(w, kbase, k_end, 1.0f, v);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_f16(GemmArgs g) {   // <=
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             g_u32x4 hi, lo;
-            gemm_split8(v[q], hi, lo);
+            gemm_split8(v[q], hi, lo, bad);
             const int off = loads_a ? la.lds_offset(w, q) : kGemmOperandBytes + lb.lds_offset(w, q);
             *reinterpret_cast<g_u32x4*>(buf + off) = hi;
             *reinterpret_cast<g_u32x4*>(buf + off + 1024) = lo;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_f16(GemmArgs g) {   // <=
         cur ^= 1;
     }
 
+    if (bad) atomicOr(&g_gemm_range_flag, 1);
     // epilogue: C/D layout of the 32x32 MFMA: lane l holds column n = l % 32, rows (r % 4) + 8 (r / 4) + 4 (l / 32)
     const float unscale = 1.0f / a_scale;
     float* C = g.C + (gridDim.z > 1 ? (size_t)blockIdx.z * g.M * g.N : 0);
@@ -297,10 +307,12 @@ __global__ void k_gemm_pack_b(PackBArgs p) {
         v[i] = (n < p.N && k < p.K) ? (p.k_strided ? p.B[(size_t)k * p.ldb + n] : p.B[(size_t)n * p.ldb + k]) : 0.0f;
     }
     g_u32x4 hi, lo;
-    gemm_split8(v, hi, lo);
+    unsigned bad = 0;
+    gemm_split8(v, hi, lo, bad);
     char* dst = p.out + (size_t)frag * 2048 + lane * 16;
     *reinterpret_cast<g_u32x4*>(dst) = hi;
     *reinterpret_cast<g_u32x4*>(dst + 1024) = lo;
+    if (bad) atomicOr(&g_gemm_range_flag, 1);
 }
 
 // Fused epilogues of the row kernel (train.hip: the layer-wise backward of the SDF and material networks).  The activation and the
@@ -390,6 +402,7 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
         const int p = blk * 32 + (r & 31);
         return p < g.e.m_pts ? (r < 32 ? p : g.e.m_pts + p) : -1;
     };
+    unsigned bad = 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         // ---- the block's rows -> split -> LDS fragment image: four segments per thread at a time, all their loads issued before
         // the first split (one HBM latency per batch instead of one per segment)
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[u][i] *= a_scale;
                 g_u32x4 hi, lo;
-                gemm_split8(v[u], hi, lo);
+                gemm_split8(v[u], hi, lo, bad);
                 // slot of (row, k-half) inside its 1-KiB fragment, rotated by the k-step within each half: a wave writes 32 chunks of ONE
                 // row at a time (that is what keeps the global loads coalesced), i.e. the same row slot of 16 different fragments --
                 // 2 KiB apart, all on the same banks; the rotation spreads those 16 over the 16 bank groups.  The reader applies the
@@ -571,6 +584,7 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
         }
         __syncthreads();   // the image is rewritten by the next block
     }
+    if (bad) atomicOr(&g_gemm_range_flag, 1);
 }
 
 template <int NTW, int EPI = kEpiPlain>

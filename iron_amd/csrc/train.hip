@@ -1351,6 +1351,20 @@ extern "C" int iron_composite_colocated_backward(float light, const float* dista
 }
 
 
+// Sticky operand-range flag of the split-fp16 GEMMs (gemm_h2.h: g_gemm_range_flag).  Synchronises `stream`.
+extern "C" int iron_train_numeric_status(int32_t reset, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int v = 0;
+    TR_HIP(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_gemm_range_flag), sizeof(int), 0, hipMemcpyDeviceToHost, st));
+    TR_HIP(hipStreamSynchronize(st));
+    if (v && reset) {
+        const int z = 0;
+        TR_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gemm_range_flag), &z, sizeof(int), 0, hipMemcpyHostToDevice, st));
+        TR_HIP(hipStreamSynchronize(st));
+    }
+    return v ? IRON_ERR_RANGE : IRON_OK;
+}
+
 extern "C" int iron_train_last_hip_error(void) { return g_hip_error; }
 extern "C" int iron_train_last_blas_status(void) { return g_blas_status; }  // kept for ABI stability: there is no BLAS any more, always 0
 

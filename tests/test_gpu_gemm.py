@@ -60,3 +60,32 @@ def test_weight_gradient_shapes(out_dim, in_dim, rows):
     print("dW [%3d x %3d] over %6d rows: rel-L2 %.2e; with beta = 1 %.2e" % (out_dim, in_dim, rows, e, rel(out_b, ref + prev.double())))
     assert e <= 5e-7 and rel(out_b, ref + prev.double()) <= 5e-7
     assert torch.equal(out, gemm(1, 0, dZ, X, out_dim, in_dim, rows))      # fixed summation order: run-to-run identical
+
+
+def test_operand_outside_the_split_range_raises_the_flag():
+    """activations / weights go into the fp16 split unscaled; an element beyond 65 504 must not pass silently
+    (include/iron_train.h: iron_train_numeric_status)."""
+    from iron_amd import autograd
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(3000, 256, generator=g).cuda()
+    W = (torch.randn(256, 256, generator=g) / 16.0).cuda()
+    autograd.numeric_status(reset=True)
+    gemm(0, 1, X, W, 3000, 256, 256)
+    assert autograd.numeric_status(reset=True) is False
+    Xb = X.clone()
+    Xb[1234, 77] = 1.0e5                                   # a forward operand (row kernel's loader)
+    out = gemm(0, 1, Xb, W, 3000, 256, 256)
+    assert not torch.isfinite(out[1234]).all()            # loud, not plausible
+    assert autograd.numeric_status(reset=False) is True   # sticky until reset
+    assert autograd.numeric_status(reset=True) is True
+    assert autograd.numeric_status(reset=True) is False
+    Wb = W.clone()
+    Wb[5, 9] = float("inf")                                # the packed operand (k_gemm_pack_b)
+    gemm(0, 1, X, Wb, 3000, 256, 256)
+    assert autograd.numeric_status(reset=True) is True
+    # a gradient operand of 1e5 is inside the range: it carries a power-of-two scale from its absolute maximum
+    dZ = (torch.randn(3000, 256, generator=g) * 1.0e5).cuda()
+    gemm(1, 0, dZ, X, 256, 256, 3000)
+    assert autograd.numeric_status(reset=True) is False
+    gemm(1, 0, dZ, Xb, 256, 256, 3000)                     # the un-scaled operand of dW (split-K kernel's loader)
+    assert autograd.numeric_status(reset=True) is True

@@ -30,8 +30,8 @@ def build(name, flags):
         return obj, subprocess.Popen([hipcc] + B.BASE_FLAGS + fl + ["-c", os.path.join(B.CSRC, src), "-o", obj],
                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
-    for src in B.SOURCES:
-        fl = list(flags) if (not only or src in only) else []
+    for src in B.SOURCES:   # every unit gets the product's flag set; the variant's flags go to all units or to VARIANT_ONLY's
+        fl = list(B.OPTIONAL_FLAGS) + list(B.SOURCE_FLAGS.get(src, [])) + (list(flags) if (not only or src in only) else [])
         obj, p = start(src, fl)
         objs.append(obj)
         procs.append((src, fl, p))
