@@ -113,7 +113,21 @@ struct BackendF32 {
     __device__ __forceinline__ bool any(bool p) { return p; }
     __device__ __forceinline__ float eval(float x, float y, float z) { return sdf_eval<kFastActT>(net, ws, x, y, z, lane); }
     __device__ __forceinline__ void finish() {}
+    // per-lane state across an evaluation: this core leaves the registers for it
+    __device__ __forceinline__ void park(int, float) {}
+    __device__ __forceinline__ void park(int, int) {}
+    __device__ __forceinline__ float unpark(int, float v) { return v; }
+    __device__ __forceinline__ int unpark(int, int v) { return v; }
 };
+
+// The h2 evaluation wants all 512 registers of a lane, so whatever a tracer kernel keeps per ray across it (origin, direction, depths,
+// counters: 15-17 values) was spilled to scratch by the compiler and re-read after every evaluation: 300+ MB of scratch writes per
+// launch reached HBM (round 2's counters: 37x the kernel's algorithmic bytes).  The kernels now put that state into LDS themselves
+// ([field][256 threads] behind the ring's map: conflict-free ds_write_b32 / ds_read_b32) and take it back after the evaluation.
+constexpr int kParkFields = 17;
+constexpr int kLdsPark = kLdsH2Total;
+constexpr int kLdsTraceTotal = kLdsPark + kParkFields * 256 * 4;   // 162 048 B of the CU's 163 840
+static_assert(kLdsTraceTotal <= 160 * 1024, "LDS of a tracer workgroup");
 
 template <bool DEFER_TILES>
 struct BackendH2T {
@@ -145,6 +159,10 @@ struct BackendH2T {
         return (row_dot_lds(lds + kLdsRows, hf, lane >> 5) + m.b_last) / m.scale;
     }
     __device__ __forceinline__ void finish() { ring.drain(); }
+    __device__ __forceinline__ void park(int i, float v) { reinterpret_cast<float*>(lds + kLdsPark)[i * 256 + threadIdx.x] = v; }
+    __device__ __forceinline__ void park(int i, int v) { reinterpret_cast<int*>(lds + kLdsPark)[i * 256 + threadIdx.x] = v; }
+    __device__ __forceinline__ float unpark(int i, float) { return reinterpret_cast<const float*>(lds + kLdsPark)[i * 256 + threadIdx.x]; }
+    __device__ __forceinline__ int unpark(int i, int) { return reinterpret_cast<const int*>(lds + kLdsPark)[i * 256 + threadIdx.x]; }
 };
 
 #ifndef IRON_TRACE_DEFER
@@ -199,7 +217,22 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sphere(IRON_TRACE_KERNEL_AR
         if (!be.any(act2 != 0u)) break;
         evals += __popc(act2);
 
+        {   // the ray state waits in LDS while the evaluation has the registers
+            const int flags = (active ? 1 : 0) | (unf ? 2 : 0) | (work ? 4 : 0) | (exhausted ? 8 : 0);
+            be.park(0, flags); be.park(1, ray); be.park(2, steps);
+            be.park(3, px); be.park(4, py); be.park(5, pz); be.park(6, dx); be.park(7, dy); be.park(8, dz); be.park(9, t); be.park(10, far);
+            be.park(11, (int)(unsigned)evals); be.park(12, (int)(evals >> 32)); be.park(13, (int)(unsigned)nconv); be.park(14, (int)(nconv >> 32));
+        }
         const float s = be.eval(px, py, pz);
+        {
+            const int flags = be.unpark(0, (active ? 1 : 0) | (unf ? 2 : 0) | (work ? 4 : 0) | (exhausted ? 8 : 0));
+            active = flags & 1; unf = flags & 2; work = flags & 4; exhausted = flags & 8;
+            ray = be.unpark(1, ray); steps = be.unpark(2, steps);
+            px = be.unpark(3, px); py = be.unpark(4, py); pz = be.unpark(5, pz); dx = be.unpark(6, dx); dy = be.unpark(7, dy); dz = be.unpark(8, dz);
+            t = be.unpark(9, t); far = be.unpark(10, far);
+            evals = (long long)(((unsigned long long)(unsigned)be.unpark(12, (int)(evals >> 32)) << 32) | (unsigned)be.unpark(11, (int)(unsigned)evals));
+            nconv = (long long)(((unsigned long long)(unsigned)be.unpark(14, (int)(nconv >> 32)) << 32) | (unsigned)be.unpark(13, (int)(unsigned)nconv));
+        }
 
         bool retire = false, to_sampler = false;
         if (active) {
@@ -376,16 +409,32 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
         const bool in_range = has_ray && idx < a.n_steps;
         const float z = sample_depth(smin, a.lin[in_range ? idx : a.n_steps - 1], width);
         const float qx = has_ray ? ox + dx * z : 0.f, qy = has_ray ? oy + dy * z : 0.f, qz = has_ray ? oz + dz * z : 0.f;  // :150
+        {   // the slot's state waits in LDS while the evaluation has the registers
+            const int flags = (has_ray ? 1 : 0) | (retired ? 2 : 0) | (publish ? 4 : 0) | (in_range ? 8 : 0);
+            be.park(0, flags); be.park(1, ray); be.park(2, blk); be.park(3, ticket);
+            be.park(4, ox); be.park(5, oy); be.park(6, oz); be.park(7, dx); be.park(8, dy); be.park(9, dz);
+            be.park(10, smin); be.park(11, width); be.park(12, prev_z); be.park(13, prev_f); be.park(14, z);
+            be.park(15, (int)(unsigned)evals); be.park(16, (int)(evals >> 32));
+        }
         const float f = be.eval(qx, qy, qz);
-        evals += __popc((unsigned)__ballot(in_range));   // lanes 32..63 mirror 0..31: the low word counts every point once
-        const unsigned neg_all = (unsigned)__ballot(in_range && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
+        const int flags_back = be.unpark(0, (has_ray ? 1 : 0) | (retired ? 2 : 0) | (publish ? 4 : 0) | (in_range ? 8 : 0));
+        has_ray = flags_back & 1; retired = flags_back & 2; publish = flags_back & 4;
+        const bool in_range_b = flags_back & 8;
+        ray = be.unpark(1, ray); blk = be.unpark(2, blk); ticket = be.unpark(3, ticket);
+        ox = be.unpark(4, ox); oy = be.unpark(5, oy); oz = be.unpark(6, oz); dx = be.unpark(7, dx); dy = be.unpark(8, dy); dz = be.unpark(9, dz);
+        smin = be.unpark(10, smin); width = be.unpark(11, width); prev_z = be.unpark(12, prev_z); prev_f = be.unpark(13, prev_f);
+        const float zb = be.unpark(14, z);
+        evals = (long long)(((unsigned long long)(unsigned)be.unpark(16, (int)(evals >> 32)) << 32) | (unsigned)be.unpark(15, (int)(unsigned)evals));
+        idle_polls = 0;
+        evals += __popc((unsigned)__ballot(in_range_b));   // lanes 32..63 mirror 0..31: the low word counts every point once
+        const unsigned neg_all = (unsigned)__ballot(in_range_b && f < 0.0f);  // sign(f) == -1 (raytracer.py:162-166)
         // the slot's neighbours' values, fetched by every lane (shuffles are wave-wide operations)
         const unsigned neg = neg_all & slot_bits;
         const int first = neg ? (__ffs(neg) - 1) : slot_lane0;          // wave lane of the slot's first negative sample
-        const float z_first = __shfl(z, first, 64), f_first = __shfl(f, first, 64);
-        const float z_before = __shfl(z, first > slot_lane0 ? first - 1 : slot_lane0, 64);
+        const float z_first = __shfl(zb, first, 64), f_first = __shfl(f, first, 64);
+        const float z_before = __shfl(zb, first > slot_lane0 ? first - 1 : slot_lane0, 64);
         const float f_before = __shfl(f, first > slot_lane0 ? first - 1 : slot_lane0, 64);
-        const float z_last = __shfl(z, slot_lane0 + kSamplerBlock - 1, 64), f_last = __shfl(f, slot_lane0 + kSamplerBlock - 1, 64);
+        const float z_last = __shfl(zb, slot_lane0 + kSamplerBlock - 1, 64), f_last = __shfl(f, slot_lane0 + kSamplerBlock - 1, 64);
         // outcome of this block for the slot (straight-line: every lane of the slot computes the same)
         const int gidx = blk * kSamplerBlock + (first - slot_lane0);          // index of the first negative sample, if any
         const bool found_neg = has_ray && neg != 0u;
@@ -469,7 +518,21 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_a(IRON_TRACE_KERNEL_
         }
         if (!be.any(has_batch)) break;
         evals += has_batch ? __popc((unsigned)__ballot(work)) : 0;
+        {   // the batch's state waits in LDS while the evaluation has the registers
+            const int flags = (has_batch ? 1 : 0) | (exhausted ? 2 : 0) | (valid ? 4 : 0) | (work ? 8 : 0);
+            be.park(0, flags); be.park(1, li); be.park(2, ray); be.park(3, k);
+            be.park(4, ox); be.park(5, oy); be.park(6, oz); be.park(7, dx); be.park(8, dy); be.park(9, dz);
+            be.park(10, lo); be.park(11, hi); be.park(12, mid); be.park(13, (int)(unsigned)evals); be.park(14, (int)(evals >> 32));
+        }
         const float f = be.eval(ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        {
+            const int flags = be.unpark(0, (has_batch ? 1 : 0) | (exhausted ? 2 : 0) | (valid ? 4 : 0) | (work ? 8 : 0));
+            has_batch = flags & 1; exhausted = flags & 2; valid = flags & 4; work = flags & 8;
+            li = be.unpark(1, li); ray = be.unpark(2, ray); k = be.unpark(3, k);
+            ox = be.unpark(4, ox); oy = be.unpark(5, oy); oz = be.unpark(6, oz); dx = be.unpark(7, dx); dy = be.unpark(8, dy); dz = be.unpark(9, dz);
+            lo = be.unpark(10, lo); hi = be.unpark(11, hi); mid = be.unpark(12, mid);
+            evals = (long long)(((unsigned long long)(unsigned)be.unpark(14, (int)(evals >> 32)) << 32) | (unsigned)be.unpark(13, (int)(unsigned)evals));
+        }
         if (has_batch) {
             if (work) {
                 if (f > 0.0f) lo = mid; else hi = mid;
@@ -525,11 +588,28 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_b(IRON_TRACE_KERNEL_
         }
         if (!be.any(has_batch)) break;
         const unsigned rem = has_batch ? (unsigned)__ballot(remaining > 0) : 0u;
-        const float qx = ox + dx * mid, qy = oy + dy * mid, qz = oz + dz * mid;
+        float qx = ox + dx * mid, qy = oy + dy * mid, qz = oz + dz * mid;
+        {   // the batch's state waits in LDS while the evaluation has the registers
+            const int flags = (has_batch ? 1 : 0) | (exhausted ? 2 : 0) | (valid ? 4 : 0);
+            be.park(0, flags); be.park(1, li); be.park(2, ray); be.park(3, remaining);
+            be.park(4, ox); be.park(5, oy); be.park(6, oz); be.park(7, dx); be.park(8, dy); be.park(9, dz);
+            be.park(10, lo); be.park(11, hi); be.park(12, mid); be.park(13, (int)(unsigned)evals); be.park(14, (int)(evals >> 32));
+            be.park(15, (int)rem);
+        }
         const float f = be.eval(qx, qy, qz);
+        {
+            const int flags = be.unpark(0, (has_batch ? 1 : 0) | (exhausted ? 2 : 0) | (valid ? 4 : 0));
+            has_batch = flags & 1; exhausted = flags & 2; valid = flags & 4;
+            li = be.unpark(1, li); ray = be.unpark(2, ray); remaining = be.unpark(3, remaining);
+            ox = be.unpark(4, ox); oy = be.unpark(5, oy); oz = be.unpark(6, oz); dx = be.unpark(7, dx); dy = be.unpark(8, dy); dz = be.unpark(9, dz);
+            lo = be.unpark(10, lo); hi = be.unpark(11, hi); mid = be.unpark(12, mid);
+            evals = (long long)(((unsigned long long)(unsigned)be.unpark(14, (int)(evals >> 32)) << 32) | (unsigned)be.unpark(13, (int)(unsigned)evals));
+            qx = ox + dx * mid; qy = oy + dy * mid; qz = oz + dz * mid;   // (the same expressions: the evaluated point)
+        }
+        const unsigned rem_b = (unsigned)be.unpark(15, (int)rem);
         if (has_batch) {
-            if (rem) {
-                evals += __popc(rem);
+            if (rem_b) {
+                evals += __popc(rem_b);
                 if (remaining > 0) {
                     if (f > 0.0f) lo = mid; else hi = mid;
                     mid = (lo + hi) / 2.0f;
@@ -650,20 +730,20 @@ static void launch_trace_kernel(int which, bool h2, const iron_net* sdf, const T
     if (h2) {
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)k_sphere<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
-            (void)hipFuncSetAttribute((const void*)k_sampler<BackendH2Sampler>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
-            (void)hipFuncSetAttribute((const void*)k_bisect_a<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
-            (void)hipFuncSetAttribute((const void*)k_bisect_b<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsH2Total);
+            (void)hipFuncSetAttribute((const void*)k_sphere<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTraceTotal);
+            (void)hipFuncSetAttribute((const void*)k_sampler<BackendH2Sampler>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTraceTotal);
+            (void)hipFuncSetAttribute((const void*)k_bisect_a<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTraceTotal);
+            (void)hipFuncSetAttribute((const void*)k_bisect_b<BackendH2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTraceTotal);
             attr = true;
         }
         const int64_t wgs = (units + 3) / 4;
         const int cus = resident_waves() / 4;
         const dim3 grid((unsigned)(wgs < cus ? wgs : cus)), block(256);
         switch (which) {
-            case 0: hipLaunchKernelGGL(k_sphere<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
-            case 1: hipLaunchKernelGGL(k_sampler<BackendH2Sampler>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
-            case 2: hipLaunchKernelGGL(k_bisect_a<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
-            default: hipLaunchKernelGGL(k_bisect_b<BackendH2>, grid, block, kLdsH2Total, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 0: hipLaunchKernelGGL(k_sphere<BackendH2>, grid, block, kLdsTraceTotal, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 1: hipLaunchKernelGGL(k_sampler<BackendH2Sampler>, grid, block, kLdsTraceTotal, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            case 2: hipLaunchKernelGGL(k_bisect_a<BackendH2>, grid, block, kLdsTraceTotal, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
+            default: hipLaunchKernelGGL(k_bisect_b<BackendH2>, grid, block, kLdsTraceTotal, st, sdf->sdf, sdf->h2_trace, m, a, w); break;
         }
     } else {
         const int waves = resident_waves();
