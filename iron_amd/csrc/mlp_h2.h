@@ -455,6 +455,10 @@ struct EpiState {
 // sched_barrier), so the producing instruction cannot float away from the place in the stream it was written at.
 __device__ __forceinline__ void pin1(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin1u(unsigned& a) { asm volatile("" : "+v"(a)); }
+// (The stages stay one element per instruction on purpose: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 halve the instruction count but a
+// packed fp32 operation beside an MFMA costs 21 cycles of matrix throughput where a plain one costs 0.7-1.3 -- 54.7 cycles per MFMA
+// with ONE v_pk_fma_f32 per gap against 35.3 with two v_fma_f32, tools/micro/mfma_gap_fill.hip, profiles/r03_mfma_gap_fill.txt --
+// and hipcc 7.2 splits the packed forms it finds between MFMAs back into scalar ones for the same reason.)
 
 // element range of part `part` (0..2) of an n-element stage: 16 -> 5/6/5, 8 -> 3/3/2
 __device__ __forceinline__ constexpr int epi_lo(int n, int part) { return n == 16 ? (part == 0 ? 0 : part == 1 ? 5 : 11) : (part == 0 ? 0 : part == 1 ? 3 : 6); }
