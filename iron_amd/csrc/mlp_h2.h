@@ -514,6 +514,57 @@ __device__ __forceinline__ void epi_stage(EpiState& st, int ks, int part, const 
     }
 }
 
+// ---- the same epilogue, scheduled by MFMA gap (softplus networks, steps without CARRY) ---------------------
+// What a vector instruction beside an MFMA costs in the micro-benchmark depends on how many share the gap (tools/micro/mfma_gap_fill.hip,
+// cycles of matrix throughput per gap: 1..4 plain 1.3 / 2.0 / 2.7 / 3.3, but 5 -> 7.3 and 6 -> 9.3; 2 transcendentals 3.3, 3 -> 9.3).
+// The stage-per-k-step pipeline above puts 5 / 6 / 5 plain or 3 / 3 / 2 transcendental instructions into the three gaps of a k-step
+// and leaves three k-steps empty (~270 cycles per step by that table); a tile's 128 plain + 32 transcendental instructions are
+// exactly 32 gaps of four + 16 gaps of two (~160 by the table).  Measured on the frame (C1, one box, interleaved runs, ms):
+//   stage per k-step (epi_stage)                                                      52.96 / 52.96   sphere 19.86  sampler 26.10
+//   the stages in order, four elements (two transcendentals) per gap, all 48 gaps     52.64 / 52.64          19.71          25.92   <- default
+//   the tile's 8 element pairs one after the other, six gaps each (dependent
+//   instructions share a gap; built, removed)                                         53.57 against 52.85 on its box: slower
+// -0.6 %, a sixth of what the table promises: the ring step is not the micro-benchmark's steady state.
+// CARRY steps keep the stage-per-k-step form (their fragments are due before k-steps 14 / 15).
+#ifndef IRON_H2_EPI_GAPS
+#define IRON_H2_EPI_GAPS 1
+#endif
+template <int EPI>
+__device__ __forceinline__ void epi_gap(EpiState& st, int g, const f32x16& p_hi, const f32x16& p_lo) {
+    constexpr float kC1 = 144.26950408889634f;            // 100 * log2(e)
+    constexpr float kC2 = 0.0069314718055994531f;         // ln(2) / 100
+    // gaps 0-3 combine | 4-7 -|z| c1 | 8-15 exp2 | 16-19 1 + e | 20-27 log2 | 28-31 max(z, 0) | 32-35 fma | 36-37 hi pairs | 38-41 residual |
+    // 42-45 scale | 46-47 lo pairs
+    if (g < 4) { _Pragma("unroll") for (int i = 4 * g; i < 4 * g + 4; ++i) { float lo = p_lo[i]; pin1(lo); st.z[i] = fmaf(lo, kLoInv, p_hi[i]); pin1(st.z[i]); } }
+    else if (g < 8) { _Pragma("unroll") for (int i = 4 * (g - 4); i < 4 * (g - 4) + 4; ++i) { st.e[i] = __builtin_fabsf(st.z[i]) * -kC1; pin1(st.e[i]); } }
+    else if (g < 16) { _Pragma("unroll") for (int i = 2 * (g - 8); i < 2 * (g - 8) + 2; ++i) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); pin1(st.e[i]); } }
+    else if (g < 20) { _Pragma("unroll") for (int i = 4 * (g - 16); i < 4 * (g - 16) + 4; ++i) { st.e[i] = 1.0f + st.e[i]; pin1(st.e[i]); } }
+    else if (g < 28) { _Pragma("unroll") for (int i = 2 * (g - 20); i < 2 * (g - 20) + 2; ++i) { st.e[i] = __builtin_amdgcn_logf(st.e[i]); pin1(st.e[i]); } }
+    else if (g < 32) { _Pragma("unroll") for (int i = 4 * (g - 28); i < 4 * (g - 28) + 4; ++i) { st.z[i] = relu_med3(st.z[i]); pin1(st.z[i]); } }
+    else if (g < 36) { _Pragma("unroll") for (int i = 4 * (g - 32); i < 4 * (g - 32) + 4; ++i) { st.z[i] = __builtin_fmaf(st.e[i], kC2, st.z[i]); pin1(st.z[i]); } }
+    else if constexpr (EPI == 1) {
+        if (g < 38) {
+            _Pragma("unroll") for (int q = 4 * (g - 36); q < 4 * (g - 36) + 4; ++q) {
+                st.hpb[q] = __builtin_bit_cast(unsigned, cvt_pk_rn(st.z[2 * q], st.z[2 * q + 1]));
+                pin1u(st.hpb[q]);
+            }
+        } else if (g < 42) {
+            _Pragma("unroll") for (int i = 4 * (g - 38); i < 4 * (g - 38) + 4; ++i) {
+                st.rr[i] = (i & 1) ? residual_hi(st.hpb[i >> 1], st.z[i]) : residual_lo(st.hpb[i >> 1], st.z[i]);
+                pin1(st.rr[i]);
+            }
+        } else if (g < 46) { _Pragma("unroll") for (int i = 4 * (g - 42); i < 4 * (g - 42) + 4; ++i) { st.rr[i] = st.rr[i] * kLoScale; pin1(st.rr[i]); } }
+        else {
+            _Pragma("unroll") for (int q = 4 * (g - 46); q < 4 * (g - 46) + 4; ++q) {
+                unsigned lp = __builtin_bit_cast(unsigned, cvt_pk_rn(st.rr[2 * q], st.rr[2 * q + 1]));
+                pin1u(lp);
+                st.oh[q >> 2][q & 3] = st.hpb[q];
+                st.ol[q >> 2][q & 3] = lp;
+            }
+        }
+    }
+}
+
 // One ring step on a hidden slot, fused with the epilogue of the previous output tile:
 //   refill `wr`;  acc += W[tile,:] * in  (48 MFMAs, fragment reads one k-step ahead);  meanwhile (VALU) the pending
 //   accumulators `p_hi/p_lo` of tile-1 go through combine + softplus (+ fp16 split) into out_prev / hf_prev.
@@ -567,12 +618,21 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
         }
         const half8 fh = fhs[ks % kSets], fl = fls[ks % kSets];
         const int ti = ks >> 1, s = ks & 1;
+        constexpr bool kByGap = IRON_H2_EPI_GAPS != 0 && ACT == 0 && !CARRY;   // softplus tiles: the gap-scheduled form (epi_gap)
         acc_hi = mfma_h(fh, in[ti].h[s], acc_hi);
-        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) {
+            if constexpr (kByGap) epi_gap<EPI>(es, 3 * ks, p_hi, p_lo); else epi_stage<EPI, ACT>(es, ks, 0, p_hi, p_lo);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         acc_lo = mfma_h(fh, in[ti].l[s], acc_lo);
-        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) {
+            if constexpr (kByGap) epi_gap<EPI>(es, 3 * ks + 1, p_hi, p_lo); else epi_stage<EPI, ACT>(es, ks, 1, p_hi, p_lo);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         acc_lo = mfma_h(fl, in[ti].h[s], acc_lo);
-        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) { epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo); }
+        if constexpr (EPI != 0 && !(IRON_H2_ABL & 2)) {
+            if constexpr (kByGap) epi_gap<EPI>(es, 3 * ks + 2, p_hi, p_lo); else epi_stage<EPI, ACT>(es, ks, 2, p_hi, p_lo);
+        }
         if constexpr (CARRY) {
             static_assert(!CARRY || EPI == 1, "a carried tile ends as split fragments");
             if (ks == 12) {
@@ -585,9 +645,11 @@ __device__ __forceinline__ void step_hidden(const char* __restrict__ rd, const c
             }
         }
 #if IRON_H2_SPREAD
-        if constexpr (EPI == 1 && !CARRY) {   // the fragments are final behind stage 12: park them in the AGPR file under the MFMAs of k-steps 13 / 14
-            if (ks == 13) asm volatile("" : "+a"(es.oh[0]), "+a"(es.ol[0]));
-            if (ks == 14) asm volatile("" : "+a"(es.oh[1]), "+a"(es.ol[1]));
+        if constexpr (EPI == 1 && !CARRY) {   // finished fragments are parked in the AGPR file under the MFMAs of k-steps 13 / 14
+            if constexpr (!kByGap) {
+                if (ks == 13) asm volatile("" : "+a"(es.oh[0]), "+a"(es.ol[0]));
+                if (ks == 14) asm volatile("" : "+a"(es.oh[1]), "+a"(es.ol[1]));
+            }
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
