@@ -43,8 +43,8 @@ def rays(n: int):
     return o, d, mid - 1.0, mid + 1.0
 
 
-def run(rays: int = 40000, batches=(4096,), repeats: int = 1, warm: bool = True):
-    """-> one dict per batch size."""
+def run(rays: int = 40000, batches=(4096,), repeats: int = 1, warm: bool = True, before_timed=None):
+    """-> one dict per batch size.  `before_timed()` runs after the warm-up frame (same networks: packed, workspaces allocated) and before the clock starts."""
     class A:
         pass
     a = A()
@@ -62,6 +62,8 @@ def run(rays: int = 40000, batches=(4096,), repeats: int = 1, warm: bool = True)
         if warm:
             frame()
         torch.cuda.synchronize()
+        if before_timed is not None:
+            before_timed()
         t0 = time.perf_counter()
         for _ in range(repeats):
             frame()
