@@ -76,6 +76,27 @@ def parse():
     return ap.parse_args()
 
 
+_JSON_OUT = None
+
+
+def _reserve_stdout():
+    """N > 1: rank 0's stdout must carry the JSON line and nothing else, and a communication backend may write notes of its own to
+    fd 1 (gloo prints its connection count there).  File descriptor 1 is pointed at stderr for the rest of the run; `emit` writes
+    to the original stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        _JSON_OUT = os.fdopen(saved, "w")
+
+
+def emit(obj) -> None:
+    out = _JSON_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -128,8 +149,8 @@ def launch_ranks(a) -> int:
                     procs[q].terminate()
         time.sleep(0.05)
     t.join(timeout=5)
-    for line in lines:
-        sys.stdout.write(line)
+    for line in lines:   # stdout carries the JSON line only (a backend's own chatter on rank 0's stdout, e.g. gloo's connection notes, goes to stderr)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     if rc == 0 and not any(l.startswith("{") for l in lines):
         print("[bench] rank 0 printed no JSON line", file=sys.stderr)
@@ -140,6 +161,7 @@ def launch_ranks(a) -> int:
 def rendezvous_only(a, world, rank):
     """The launch protocol without a render: join the group, count the ranks with an all-reduce, print the launch fields."""
     import torch.distributed as dist
+    _reserve_stdout()
     backend = os.environ.get("IRON_BENCH_BACKEND", "nccl")
     if backend == "nccl":
         dev = torch.device("cuda", 0 if os.environ.get("IRON_BENCH_ONE_GPU", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
@@ -151,8 +173,8 @@ def rendezvous_only(a, world, rank):
         one = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(one)
     if rank == 0:
-        print(json.dumps({"rendezvous_only": True, "n_gpus": a.gpus, "ranks_seen": dist.get_world_size(), "ranks_counted": int(one.item()),
-                          "backend": backend, "launcher": os.environ.get("IRON_BENCH_LAUNCHER", "torchrun")}), flush=True)
+        emit({"rendezvous_only": True, "n_gpus": a.gpus, "ranks_seen": dist.get_world_size(), "ranks_counted": int(one.item()),
+              "backend": backend, "launcher": os.environ.get("IRON_BENCH_LAUNCHER", "torchrun")})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -465,6 +487,7 @@ def main():
     one_gpu = os.environ.get("IRON_BENCH_ONE_GPU", "0") == "1"
     dev_index = 0 if (world == 1 or one_gpu) else local_rank
     if world > 1:
+        _reserve_stdout()
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -662,7 +685,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.scene, a.cpu_sample_res)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
