@@ -219,6 +219,44 @@ def test_stage_methods_match_the_oracle():
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("n_steps", [9, 31, 32, 33, 64, 100, 128, 200])
+def test_sampler_work_items_at_any_step_count(n_steps):
+    """k_sampler marches a ray as work items of 32 samples and hands the rest of an unfinished ray to the queue (trace.hip): step
+    counts that end inside a block, inside an item, exactly on an item boundary and beyond 128 must all give the reference's root
+    (first sign change of the n_steps samples, raytracer.py:142-197), and the whole trace with that n_steps the oracle's result."""
+    from iron_amd.raytracer import Camera, RayTracer, SDFHandle, intersect_sphere
+    dev = torch.device("cuda", 0)
+    nets_cpu = scenes.build_networks("S1")
+    sc = oracle_scene(nets_cpu)
+    net = nets_cpu["sdf_network"].to(dev)
+    K, W2C = scenes.fixture_camera_matrices(64, 64)
+    cam = Camera(64, 64, K.to(dev), W2C.to(dev))
+    ro, rd, _ = cam.get_rays(cam.get_uv())
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    hit, near, far = intersect_sphere(ro, rd, 1.0)
+    m = hit.cpu()
+    prm = R.TracerParams(n_steps=n_steps)
+    sdf_fn = lambda x: R.sdf_forward(sc.sdf_sd, sc.sdf_spec, x)[:, 0]
+    c_ro, c_rd, c_near, c_far = ro.cpu()[m], rd.cpu()[m], near.cpu()[m], far.cpu()[m]
+    # every ray that meets the bounding sphere, sampled over [near, far]: roots early, late and never
+    rroot, rsp, rss, rst, _ = R.ray_sampler(sdf_fn, c_ro, c_rd, c_near.clone(), c_far.clone(), prm)
+    tr = RayTracer(n_steps=n_steps)
+    root, sp, ss, st = tr.ray_sampler(SDFHandle(net), c_ro.to(dev), c_rd.to(dev), c_near.to(dev), c_far.to(dev))
+    assert int((root.cpu() != rroot).sum()) <= 2, (n_steps, int((root.cpu() != rroot).sum()))
+    both = root.cpu() & rroot
+    assert int(both.sum()) > 100
+    assert float((st.cpu() - rst)[both].abs().max()) <= 2e-4 and float((sp.cpu() - rsp)[both].abs().max()) <= 2e-4
+    nor = ~root.cpu() & ~rroot
+    assert float(st.cpu()[nor].abs().max()) == 0.0 and float(ss.cpu()[nor].abs().max()) == 0.0
+    # an empty list and a one-ray list go through the same queue
+    e = torch.empty(0, 3, device=dev)
+    r0 = tr.ray_sampler(SDFHandle(net), e, e, torch.empty(0, device=dev), torch.empty(0, device=dev))
+    assert r0[0].numel() == 0
+    r1 = tr.ray_sampler(SDFHandle(net), c_ro[:1].to(dev), c_rd[:1].to(dev), c_near[:1].to(dev), c_far[:1].to(dev))
+    assert bool(r1[0].cpu()[0]) == bool(rroot[0]) and abs(float(r1[3].cpu()[0]) - float(rst[0])) <= 2e-4
+
+
+@torch.no_grad()
 def test_h2_tracer_agrees_with_the_exact_core_on_a_fixed_ray_set():
     """Tripwire for the compiler option the default build depends on (-mllvm -amdgpu-mfma-vgpr-form=1 has miscompiled k_sampler
     once: 17 of 88 056 roots lost): the same rays through the h2 kernels and through the exact-fp32 kernels of the
