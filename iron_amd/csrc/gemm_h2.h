@@ -282,6 +282,14 @@ static inline hipError_t gemm_split_launch(const GemmArgs& g, int splits, hipStr
 // The small operand B (the layer's weight matrix) is split ONCE per GEMM by k_gemm_pack_b into fragments in global memory
 // ([col tile][k-step][hi, lo] x 1 KiB); every wave streams its own column tiles' fragments straight from L2 into registers -- each
 // B byte is used by exactly one wave of the workgroup, so LDS would add nothing.
+// Where its time goes (round 3, 131 072 x 256 x 256 on one box: 103 us = 2.6 TB/s of A in + C out; a device copy of the same bytes
+// takes 37 us = 7.2 TB/s): with the B fragments served from L1 94 us, without the C stores 80, without the A loads 76, without all
+// three 49 -- the phases of a workgroup (rows -> split -> LDS | MFMAs, B three k-steps deep from L2 | stores) run one after the other
+// and two workgroups per CU cover each other only in part.  Neither a deeper loader (8 segments per thread: 105), a larger or
+// smaller grid (256: 130, 512 / 2048: 101-103), the vgpr-form option (106), eight waves of half the accumulators (spills; C3 slower),
+// nor a weight-stationary form (one workgroup per CU keeping all B fragments in 256 registers, rows by LDS-DMA under the previous
+// block's MFMAs, split pass from LDS: 133 us -- split pass 52, DMA issue 25, epilogue 22 of it, nothing to cover them at four waves
+// per CU) beat it; what would is a producer / consumer split of the workgroup's waves, not built.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kRowsBM = 64;
 constexpr int kRowsMaxKSteps = 24;   // K <= 384
@@ -384,6 +392,101 @@ __device__ __forceinline__ void publish_absmax(float m, float* out) {
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
 }
 
+// global row of block row r (0..63) of block `blk`, or -1
+__device__ __forceinline__ int rows_row_of(const RowsArgs& g, bool paired, int blk, int r) {
+    if (!paired) { const int gr = blk * kRowsBM + r; return gr < g.R ? gr : -1; }
+    const int p = blk * 32 + (r & 31);
+    return p < g.e.m_pts ? (r < 32 ? p : g.e.m_pts + p) : -1;
+}
+
+// the block's accumulators -> C (plain) or the fused activation / activation-gradient outputs (see above)
+template <int NTW, int EPI>
+__device__ __forceinline__ void rows_epilogue(const RowsArgs& g, int blk, bool paired, float unscale, int nt0, int lane,
+                                              g_f32x16 (&acc_hi)[2][NTW], g_f32x16 (&acc_lo)[2][NTW]) {
+    auto row_of = [&](int b, int r) -> int { return rows_row_of(g, paired, b, r); };
+    if constexpr (EPI == kEpiPlain) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = (nt0 + j) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = blk * kRowsBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < g.R && n < g.N) {
+                        const float v = fmaf(acc_lo[i][j][r], kGemmLoInv, acc_hi[i][j][r]) * unscale;
+                        float* dst = g.C + (size_t)m * g.ldc + n;
+                        *dst = g.beta != 0.0f ? fmaf(g.beta, *dst, v) : v;
+                    }
+                }
+            }
+    } else {
+        const RowsEpi& e = g.e;
+        float mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (nt0 + j) * 32 + (lane & 31);
+            const bool col_ok = n < e.n_act;
+            const float bias = (col_ok && (EPI == kEpiSdfAct || EPI == kEpiReluAct)) ? e.bias[n] : 0.0f;
+            float colsum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v0 = fmaf(acc_lo[0][j][r], kGemmLoInv, acc_hi[0][j][r]) * unscale;
+                const float v1 = fmaf(acc_lo[1][j][r], kGemmLoInv, acc_hi[1][j][r]) * unscale;
+                const int m0 = row_of(blk, rr), m1 = row_of(blk, 32 + rr);
+                if (!col_ok) continue;
+                if constexpr (EPI == kEpiSdfAct) {
+                    if (paired) {   // (z, zdot) of one point
+                        if (m0 >= 0) {
+                            const float z = v0 + bias;
+                            float a, s1, s2;
+                            softplus100_fast(z, &a, &s1, &s2);
+                            e.Z[(size_t)m0 * e.ldz + n] = z;
+                            e.Z[(size_t)m1 * e.ldz + n] = v1;
+                            e.out[(size_t)m0 * e.ld_out + n] = a * e.sc;
+                            e.out[(size_t)m1 * e.ld_out + n] = s1 * v1 * e.sc;
+                        }
+                    } else {
+                        float a, s1, s2;
+                        if (m0 >= 0) { const float z = v0 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = a * e.sc; }
+                        if (m1 >= 0) { const float z = v1 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = a * e.sc; }
+                    }
+                } else if constexpr (EPI == kEpiSdfBack) {
+                    if (paired) {
+                        if (m0 >= 0) {
+                            float a, s1, s2;
+                            softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2);
+                            const float abar = v0 * e.sc, adotbar = v1 * e.sc;
+                            const float zd = e.Z[(size_t)m1 * e.ldz + n];
+                            const float zbar = s1 * abar + s2 * zd * adotbar, tbar = s1 * adotbar;
+                            e.out[(size_t)m0 * e.ld_out + n] = zbar;
+                            e.out[(size_t)m1 * e.ld_out + n] = tbar;
+                            colsum += zbar;
+                            mx = fmaxf(mx, fmaxf(fabsf(zbar), fabsf(tbar)));
+                        }
+                    } else {
+                        float a, s1, s2;
+                        if (m0 >= 0) { softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v0 * e.sc); e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                        if (m1 >= 0) { softplus100_fast(e.Z[(size_t)m1 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v1 * e.sc); e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                    }
+                } else if constexpr (EPI == kEpiReluAct) {
+                    if (m0 >= 0) { const float z = v0 + bias; e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
+                    if (m1 >= 0) { const float z = v1 + bias; e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
+                } else {   // kEpiReluBack
+                    if (m0 >= 0) { const float zb = e.Z[(size_t)m0 * e.ldz + n] > 0.0f ? v0 * e.sc : 0.0f; e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                    if (m1 >= 0) { const float zb = e.Z[(size_t)m1 * e.ldz + n] > 0.0f ? v1 * e.sc : 0.0f; e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
+                }
+            }
+            if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) {
+                colsum += __shfl_xor(colsum, 32, 64);   // the two lane halves hold the other rows of the same column
+                if (lane < 32 && col_ok && e.db) atomicAdd(&e.db[n], colsum);
+            }
+        }
+        if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) publish_absmax(mx, e.amax_out);
+    }
+}
+
 // NTW = column tiles (of 32) per wave: the workgroup covers 4 * NTW * 32 columns
 template <int NTW, int EPI = kEpiPlain>
 __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs g) {   // NTW <= 2: <= 256 registers, two workgroups per CU
@@ -396,12 +499,7 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
     const int n_seg = kRowsBM * k_chunks;                  // segments of the 64-row block
     const bool paired = EPI != kEpiPlain && g.e.paired != 0;
     const int n_blocks = paired ? (g.e.m_pts + 31) / 32 : (g.R + kRowsBM - 1) / kRowsBM;
-    // global row of block row r (0..63), or -1
-    auto row_of = [&](int blk, int r) -> int {
-        if (!paired) { const int gr = blk * kRowsBM + r; return gr < g.R ? gr : -1; }
-        const int p = blk * 32 + (r & 31);
-        return p < g.e.m_pts ? (r < 32 ? p : g.e.m_pts + p) : -1;
-    };
+    auto row_of = [&](int blk, int r) -> int { return rows_row_of(g, paired, blk, r); };
     unsigned bad = 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         // ---- the block's rows -> split -> LDS fragment image: four segments per thread at a time, all their loads issued before
@@ -501,87 +599,7 @@ __global__ __launch_bounds__(256, (NTW <= 2 ? 2 : 1)) void k_gemm_rows(RowsArgs 
             }
         }
         // ---- epilogue
-        if constexpr (EPI == kEpiPlain) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int n = (nt0 + j) * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = blk * kRowsBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (m < g.R && n < g.N) {
-                            const float v = fmaf(acc_lo[i][j][r], kGemmLoInv, acc_hi[i][j][r]) * unscale;
-                            float* dst = g.C + (size_t)m * g.ldc + n;
-                            *dst = g.beta != 0.0f ? fmaf(g.beta, *dst, v) : v;
-                        }
-                    }
-                }
-        } else {
-            const RowsEpi& e = g.e;
-            float mx = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int n = (nt0 + j) * 32 + (lane & 31);
-                const bool col_ok = n < e.n_act;
-                const float bias = (col_ok && (EPI == kEpiSdfAct || EPI == kEpiReluAct)) ? e.bias[n] : 0.0f;
-                float colsum = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float v0 = fmaf(acc_lo[0][j][r], kGemmLoInv, acc_hi[0][j][r]) * unscale;
-                    const float v1 = fmaf(acc_lo[1][j][r], kGemmLoInv, acc_hi[1][j][r]) * unscale;
-                    const int m0 = row_of(blk, rr), m1 = row_of(blk, 32 + rr);
-                    if (!col_ok) continue;
-                    if constexpr (EPI == kEpiSdfAct) {
-                        if (paired) {   // (z, zdot) of one point
-                            if (m0 >= 0) {
-                                const float z = v0 + bias;
-                                float a, s1, s2;
-                                softplus100_fast(z, &a, &s1, &s2);
-                                e.Z[(size_t)m0 * e.ldz + n] = z;
-                                e.Z[(size_t)m1 * e.ldz + n] = v1;
-                                e.out[(size_t)m0 * e.ld_out + n] = a * e.sc;
-                                e.out[(size_t)m1 * e.ld_out + n] = s1 * v1 * e.sc;
-                            }
-                        } else {
-                            float a, s1, s2;
-                            if (m0 >= 0) { const float z = v0 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = a * e.sc; }
-                            if (m1 >= 0) { const float z = v1 + bias; softplus100_fast(z, &a, &s1, &s2); e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = a * e.sc; }
-                        }
-                    } else if constexpr (EPI == kEpiSdfBack) {
-                        if (paired) {
-                            if (m0 >= 0) {
-                                float a, s1, s2;
-                                softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2);
-                                const float abar = v0 * e.sc, adotbar = v1 * e.sc;
-                                const float zd = e.Z[(size_t)m1 * e.ldz + n];
-                                const float zbar = s1 * abar + s2 * zd * adotbar, tbar = s1 * adotbar;
-                                e.out[(size_t)m0 * e.ld_out + n] = zbar;
-                                e.out[(size_t)m1 * e.ld_out + n] = tbar;
-                                colsum += zbar;
-                                mx = fmaxf(mx, fmaxf(fabsf(zbar), fabsf(tbar)));
-                            }
-                        } else {
-                            float a, s1, s2;
-                            if (m0 >= 0) { softplus100_fast(e.Z[(size_t)m0 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v0 * e.sc); e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
-                            if (m1 >= 0) { softplus100_fast(e.Z[(size_t)m1 * e.ldz + n], &a, &s1, &s2); const float zb = s1 * (v1 * e.sc); e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
-                        }
-                    } else if constexpr (EPI == kEpiReluAct) {
-                        if (m0 >= 0) { const float z = v0 + bias; e.Z[(size_t)m0 * e.ldz + n] = z; e.out[(size_t)m0 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
-                        if (m1 >= 0) { const float z = v1 + bias; e.Z[(size_t)m1 * e.ldz + n] = z; e.out[(size_t)m1 * e.ld_out + n] = fmaxf(z, 0.0f) * e.sc; }
-                    } else {   // kEpiReluBack
-                        if (m0 >= 0) { const float zb = e.Z[(size_t)m0 * e.ldz + n] > 0.0f ? v0 * e.sc : 0.0f; e.out[(size_t)m0 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
-                        if (m1 >= 0) { const float zb = e.Z[(size_t)m1 * e.ldz + n] > 0.0f ? v1 * e.sc : 0.0f; e.out[(size_t)m1 * e.ld_out + n] = zb; colsum += zb; mx = fmaxf(mx, fabsf(zb)); }
-                    }
-                }
-                if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) {
-                    colsum += __shfl_xor(colsum, 32, 64);   // the two lane halves hold the other rows of the same column
-                    if (lane < 32 && col_ok && e.db) atomicAdd(&e.db[n], colsum);
-                }
-            }
-            if constexpr (EPI == kEpiSdfBack || EPI == kEpiReluBack) publish_absmax(mx, e.amax_out);
-        }
+        rows_epilogue<NTW, EPI>(g, blk, paired, unscale, nt0, lane, acc_hi, acc_lo);
         __syncthreads();   // the image is rewritten by the next block
     }
     if (bad) atomicOr(&g_gemm_range_flag, 1);
@@ -599,5 +617,6 @@ static inline hipError_t gemm_rows_launch(const RowsArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm_rows<NTW, EPI>), dim3(n_blocks < 1024 ? n_blocks : 1024), dim3(256), lds, st, g);
     return hipGetLastError();
 }
+
 
 }  // namespace iron_train
