@@ -815,7 +815,10 @@ def render_camera(camera, sdf_network, raytracer, color_network_dict, render_fn,
 # edge points stays in front of both, at full width: it is ~250 workgroup-tiles of work on the depth-edge candidates, and the hits
 # are shaded with the edge pixels already out of the convergent mask, exactly the reference's order (raytracer.py:586-588, 800-812).
 EDGE_OVERLAP = os.environ.get("IRON_EDGE_OVERLAP", "1") != "0"
-EDGE_SIDE_CUS = int(os.environ.get("IRON_EDGE_SIDE_CUS", "48"))   # CUs of the side-ray stream (one workgroup traces 128 rays)
+# CUs of the side-ray stream (one workgroup traces 128 rays).  Round 3: the hits' shading got twice as fast (reverse-mode get_all), so the
+# side chain -- its sampler is throughput-bound on few CUs -- is the longer branch now: 800x800 frame 63.6 / 62.9 / 61.9-62.8 / 62.5 / 63.2 ms
+# with 48 / 64 / 80 / 96 / 128 side CUs on one box (the plain frame: 53.9)
+EDGE_SIDE_CUS = int(os.environ.get("IRON_EDGE_SIDE_CUS", "96"))
 _side_streams = {}
 
 
