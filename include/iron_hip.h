@@ -313,7 +313,7 @@ typedef struct iron_trace_stats { /* written to DEVICE memory, all int64 */
                               evals + 128 per sampled ray + (chunk count + 1) per bisected ray
                               (SURVEY 8d's E; the HIP sampler stops early, so n_evals <= n_evals_ref) */
     int64_t n_evals_sphere;/* evaluations made by the sphere-tracing kernel                     */
-    int64_t reserved;
+    int64_t reserved;          /* 0; non-zero = k_sampler workgroups that left their work queue by the poll bound (a bug: report it) */
 } iron_trace_stats;
 
 size_t iron_trace_workspace_bytes(int64_t n, const iron_trace_params* p);

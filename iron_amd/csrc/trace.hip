@@ -52,7 +52,7 @@ struct TraceCounters {  // zeroed at the start of every call
     long long n_evals;
     long long n_sphere_conv;
     long long n_evals_sphere;
-    long long pad2;
+    long long sampler_abort;   // k_sampler workgroups that left the queue protocol by the poll bound (0 unless the protocol is broken)
 };
 
 struct TraceWs {
@@ -401,7 +401,11 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_sampler(IRON_TRACE_KERNEL_A
             // no ray in the workgroup: done when no slot holds a ticket that can still be served
             const bool all_ended = __hip_atomic_load(&w.cnt->n_sampler_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_list;
             const bool waiting = __ballot(ticket >= 0 || publish) != 0ull && !all_ended;
-            if (!be.any(waiting) || ++idle_polls > (1u << 22)) break;   // (the bound: a few seconds; never reached unless the protocol is broken)
+            if (!be.any(waiting)) break;
+            if (++idle_polls > (1u << 22)) {   // the bound: a few seconds; never reached unless the protocol is broken -- reported in the stats
+                if (threadIdx.x == 0) atomicAdd((unsigned long long*)&w.cnt->sampler_abort, 1ull);
+                break;
+            }
             __builtin_amdgcn_s_sleep(16);
             continue;
         }
@@ -636,11 +640,12 @@ __global__ __launch_bounds__(BE::kThreads, 1) void k_bisect_b(IRON_TRACE_KERNEL_
 constexpr size_t kCntStride = 256;
 __global__ void k_trace_stats(TraceWs w, int n_parts, int n_steps, iron_trace_stats* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long n_evals = 0, n_sphere_conv = 0, n_sampler = 0, n_root = 0, n_evals_sphere = 0;
+        long long n_evals = 0, n_sphere_conv = 0, n_sampler = 0, n_root = 0, n_evals_sphere = 0, n_abort = 0;
         for (int p = 0; p < n_parts; ++p) {
             const TraceCounters* c = (const TraceCounters*)((const char*)w.cnt + (size_t)p * kCntStride);
             n_evals += c->n_evals; n_sphere_conv += c->n_sphere_conv; n_sampler += c->n_sampler; n_root += c->n_root;
             n_evals_sphere += c->n_evals_sphere;
+            n_abort += c->sampler_abort;
         }
         out->n_evals = n_evals;
         out->n_sphere_conv = n_sphere_conv;
@@ -651,7 +656,7 @@ __global__ void k_trace_stats(TraceWs w, int n_parts, int n_steps, iron_trace_st
         for (int c = 0; c < w.n_chunks; ++c) e += (long long)w.chunk_roots[c] * (w.chunk_iters[c] + 1);
         out->n_evals_ref = e;
         out->n_evals_sphere = n_evals_sphere;
-        out->reserved = 0;
+        out->reserved = n_abort;   // k_sampler workgroups that gave up polling (iron_hip.h)
     }
 }
 

@@ -85,6 +85,13 @@ def _linspace_steps(n_steps: int, device) -> torch.Tensor:
     return torch.linspace(0, 1, steps=n_steps).float().to(device)
 
 
+def _check_stats(stats) -> None:
+    """`reserved` counts k_sampler workgroups that gave up polling their work queue (csrc/trace.hip): never, unless the queue protocol
+    is broken -- then the trace is incomplete and must not pass as a result."""
+    if stats.get("reserved", 0):
+        raise _lib.IronError("k_sampler left its work queue by the poll bound (%d workgroups): the trace is incomplete" % stats["reserved"])
+
+
 class RayTracer(nn.Module):
     def __init__(self, sdf_threshold=5.0e-5, sphere_tracing_iters=16, n_steps=128, max_num_pts=200000):
         super().__init__()
@@ -135,6 +142,7 @@ class RayTracer(nn.Module):
                                       ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)))
         if collect_stats:
             self.last_stats = dict(zip(_lib.TRACE_STATS_FIELDS, stats.cpu().tolist()))
+            _check_stats(self.last_stats)
         return {"convergent_mask": conv, "points": points, "sdf": sdf_out, "distance": dist}
 
 
@@ -239,6 +247,7 @@ class RayTracer(nn.Module):
                 _lib.check(_lib.load().iron_trace_phase(1, *state["args"]))
         if state["stats"] is not None:
             self.last_stats = dict(zip(_lib.TRACE_STATS_FIELDS, state["stats"].cpu().tolist()))
+            _check_stats(self.last_stats)
         return state["out"]
 
     @torch.no_grad()

@@ -44,6 +44,7 @@ def test_fullsize_work_counts_match_oracle(frame800):
     assert abs(H - wc["H"]) <= 8, (H, wc["H"])                       # a handful of silhouette flips at most
     assert abs(st["n_evals_ref"] - wc["E"]) <= wc["E"] * 1e-4         # same algorithm, same work
     assert st["n_evals"] <= st["n_evals_ref"]                          # early exit only removes work
+    assert st["reserved"] == 0                                       # no k_sampler workgroup gave up polling its work queue
     assert abs(st["n_sampler"] - wc["n_sampler"]) <= 16
 
 
