@@ -312,6 +312,7 @@ static inline int64_t sampler_cont_cap(int64_t n, int n_steps) {
     const int64_t blocks = (n_steps + kSamplerBlock - 1) / kSamplerBlock;
     if (n + 2 >= (1ll << kContRayBits) || blocks >= (1ll << kContBlkBits)) return 0;
     const int64_t segs = (blocks + kSamplerSeg - 1) / kSamplerSeg;
+    if (n * (segs - 1) * 8 > (256ll << 20)) return 0;   // (unusual step counts on a large call: not worth more than 256 MiB of workspace)
     return n * (segs - 1);
 }
 
