@@ -21,6 +21,7 @@ def test_gpus_n_without_torchrun_starts_n_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    assert r.stdout.strip() == lines[0], "stdout must carry the JSON line and nothing else (gloo's connection notes go to stderr): %r" % r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["ranks_counted"] == 2
     assert d["launcher"] == "self" and d["backend"] == "gloo"
@@ -37,6 +38,7 @@ def test_three_ranks_and_the_torchrun_form_agree():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ranks_counted"] == 2 and d["launcher"] == "torchrun"
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, "rank 0 prints one line under torchrun too: %r" % r.stdout
 
 
 def test_a_failing_rank_fails_the_launcher():
